@@ -1,0 +1,266 @@
+/*
+ * mivp.h -- C ABI of the MI355X-native (gfx950) Swin-UNETR hot path.
+ *
+ * Drop-in boundary: the reference has no FFI of its own -- its
+ * hot path is eager PyTorch inside `SwinUnetR.forward` -- so these entry points
+ * are what a binding from the reference's Python would call (ctypes stub in
+ * INTEGRATION.md).  Each entry cites the reference lines it replaces (paths
+ * relative to /root/reference/src/modules).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless it is a descriptor struct;
+ *  - activations are bf16, channels-last `[B, H, W, D, C]` ("NDHWC");
+ *  - parameters arrive as bf16 (GEMM weights, `[out][in]` row-major like
+ *    nn.Linear.weight) or fp32 (norm scale/shift, biases);
+ *  - no allocation, no host sync, no global state inside any call: the caller
+ *    owns every buffer (torch allocations in the Python host) and passes the
+ *    HIP stream to launch on; calls are thread-compatible;
+ *  - return 0 on success, negative MIVP_E* on error; nothing throws.
+ *
+ * Window index tables (`tok_src`, `tok_dst`, `tok_rid`) are immutable per
+ * (dims, window, shift) and are built by the host exactly as SURVEY Appendix
+ * A.1 states (swin_transformer/swin_block.py:145-178,247-253,292-364):
+ *    tok_src[P*Nqp]  voxel offset (h*W+w)*D+d inside one volume of x that feeds
+ *                    token (window, slot); -1 = zero-pad token; -2 = slot >= Nq
+ *    tok_dst[P*Nqp]  voxel offset in the block OUTPUT that the token writes; -1 = cropped
+ *    tok_rid[P*Nqp]  int32 region id of the token for the shift mask
+ * with Nqp = Nq rounded up to 16.
+ */
+#ifndef MIVP_H
+#define MIVP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mivp_stream_t;     /* hipStream_t */
+
+#define MIVP_OK            0
+#define MIVP_EINVAL       -1     /* bad argument / shape contract violated          */
+#define MIVP_EUNSUPPORTED -2     /* shape outside the instantiated kernel set       */
+#define MIVP_ELAUNCH      -3     /* hipLaunch reported an error                     */
+
+/* library identity: returns the ABI version (bumped on any signature change) */
+int mivp_abi_version(void);
+/* last HIP error string for MIVP_ELAUNCH (static storage, never NULL) */
+const char* mivp_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* Swin block (swin_block.py:145-255, window_attention.py:35-61)             */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpSwinDesc {
+    int32_t B;          /* batch                                              */
+    int32_t C;          /* channels, multiple of 8                            */
+    int32_t heads;      /* C % heads == 0, (C/heads) % 4 == 0                  */
+    int32_t vol_in;     /* H*W*D of the block input  (voxels per volume)       */
+    int32_t vol_out;    /* H*W*D of the block output (== vol_in)               */
+    int32_t P;          /* windows per volume                                  */
+    int32_t Nq;         /* tokens per window                                   */
+    int32_t Nqp;        /* Nq rounded up to 16                                 */
+    int32_t Np;         /* prompt tokens (0 = none)                            */
+    int32_t Npp;        /* rows of the prompt K/V buffers (>= Np, multiple of 16) */
+    int32_t Nkp;        /* key rows the attention kernel sees: multiple of 32, >= Nqp+Npp */
+    int32_t aug;        /* bias augmentation dims  w0 + w1 + (w2-1)            */
+    int32_t augp;       /* aug rounded up to 4                                 */
+    int32_t has_mask;   /* 1 for a shifted block                               */
+    int32_t win[3];     /* window size per axis                                */
+    float   q_scale;    /* head_dim ** -0.5                                    */
+    float   ln_eps;     /* 1e-6                                                */
+} MivpSwinDesc;
+
+/* gather + LayerNorm + q/k/v projections  (swin_block.py:205-214, window_attention.py:42-47)
+ *   x [B, vol_in, C] bf16;  ln_w, ln_b [C] f32;  wqkv [3C][C] bf16 (to_q, to_k, to_v stacked)
+ *   q, k, v [B*P][heads][Nqp][hd] bf16 ; q is pre-multiplied by q_scale ; slots >= Nq are zero */
+int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_src,
+                      const float* ln_w, const float* ln_b, const void* wqkv,
+                      void* q, void* k, void* v, mivp_stream_t stream);
+
+/* prompt tokens -> LayerNorm -> to_k / to_v, once per block
+ *   prompt [Np][C] f32 (the nn.Parameter) -> kp, vp [heads][Npp][hd] bf16 (rows >= Np zero)
+ *   yln [Np][C] f32: the normalised prompt, saved for backward                            */
+int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* ln_w, const float* ln_b,
+                       const void* wqkv, void* kp, void* vp, float* yln, mivp_stream_t stream);
+
+/* relative-position bias as MFMA augmentation dims (relative_positional_encoding.py:99-142)
+ *   t_h [heads][2*w0-1], t_w, t_d: per-axis relative tables  T_a[h][j-i+w_a-1] = s/3 * W_a[h] . E_a[...]
+ *   (scale embed_dim**-0.5 and the /3 already applied by the host), ts [heads][Np] f32 prompt-token
+ *   scores (scaled), or NULL when Np == 0.
+ *   Because the bias is a sum of three terms that each depend on ONE slot coordinate of the query, it
+ *   equals <onehot(query coords), table values at the key coords>: the kernel emits that as extra K
+ *   columns of the QK^T MFMA:   qa [Nqp][augp] bf16 (query one-hots),  ka [heads][Nkp][augp] bf16. */
+int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, const float* t_d,
+                     const float* ts, void* qa, void* ka, mivp_stream_t stream);
+
+/* softmax((q k^T + bias) * mask) v per (window, head)  (window_attention.py:49-59)
+ *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 */
+int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
+                      const void* kp, const void* vp, const void* qa, const void* ka,
+                      const int32_t* tok_rid, void* o, float* lse, mivp_stream_t stream);
+
+/* proj + residual, drop prompts, LayerNorm + Linear + residual, scatter + crop
+ * (window_attention.py:60, swin_block.py:221-253)
+ *   t1 [B*P][Nqp][C] bf16 (saved for backward, may be NULL) ; y [B, vol_out, C] bf16 */
+int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x,
+                           const int32_t* tok_src, const int32_t* tok_dst,
+                           const void* wproj, const float* bproj, const float* ln_w, const float* ln_b,
+                           const void* wmlp, const float* bmlp, void* t1, void* y, mivp_stream_t stream);
+
+/* ---- backward of the block: data gradients + prompt / token-bias gradients ---- */
+/* dy [B, vol_out, C] bf16 -> dO [B*P][Nqp][C] bf16 and dt1 [B*P][Nqp][C] bf16
+ *   wmlp_t = mlp.weight^T, wproj_t = proj.weight^T  ([in][out] -> rows are input channels) */
+int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
+                           const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
+                           void* d_o, void* d_t1, mivp_stream_t stream);
+
+/* delta[bp][head][n] = sum_j dO * O  (flash-attention backward row term) */
+int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
+                        mivp_stream_t stream);
+
+/* query-owner pass: dq [B*P][heads][Nqp][hd] bf16 (w.r.t. the stored, pre-scaled q) */
+int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
+                         const void* kp, const void* vp, const void* qa, const void* ka,
+                         const int32_t* tok_rid, const void* d_o, const float* lse, const float* delta,
+                         void* dq, mivp_stream_t stream);
+
+/* key-owner pass: dk, dv [B*P][heads][Nqp][hd] bf16 for window keys;
+ *   dkp_part, dvp_part [B*P][heads][Npp][hd] f32 and dtok_part [B*P][heads][Npp] f32:
+ *   per-window partial sums for the prompt keys (reduced by mivp_reduce_rows)            */
+int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
+                          const void* kp, const void* vp, const void* qa, const void* ka,
+                          const int32_t* tok_rid, const void* d_o, const float* lse, const float* delta,
+                          void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
+                          mivp_stream_t stream);
+
+/* dq,dk,dv -> (x W^T backward) -> LayerNorm backward -> + dt1 -> scatter to dx [B, vol_in, C] bf16
+ *   wqkv_t [C][3C] bf16 = stacked weight transposed; q part is multiplied by q_scale inside */
+int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv,
+                      const void* x, const int32_t* tok_src, const float* ln_w, const float* ln_b,
+                      const void* wqkv_t, const void* d_t1, void* dx, mivp_stream_t stream);
+
+/* prompt K/V gradients -> through to_k/to_v and LayerNorm -> dprompt [Np][C] f32
+ *   dkp, dvp [heads][Npp][hd] f32 (already reduced over windows) ; wqkv [3C][C] bf16 */
+int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const float* dvp, const float* prompt,
+                       const float* ln_w, const float* ln_b, const void* wqkv, float* dprompt,
+                       mivp_stream_t stream);
+
+/* out[r] = sum_i in[i][r]  for i < n, r < rows  (deterministic two-level tree) */
+int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Patch merging (swin_transformer/down.py:21-53)                           */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpMergeDesc {
+    int32_t B, C;               /* input channels (multiple of 8)                      */
+    int32_t dims[3];            /* input H, W, D                                       */
+    int32_t odims[3];           /* output dims                                         */
+    int32_t merge_last;         /* 1: 2x2x2 -> 8C ; 0: 2x2x1 -> 4C                     */
+    int32_t Cout;               /* output channels                                     */
+    float   ln_eps;
+} MivpMergeDesc;
+/* x [B,H,W,D,C] bf16 -> y [B,oh,ow,od,Cout] bf16 ; w [Cout][kC] bf16 ; ln over kC */
+int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const float* ln_w, const float* ln_b,
+                         const void* w, void* y, mivp_stream_t stream);
+/* dy -> dx ; w_t [kC][Cout] bf16 */
+int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
+                         const float* ln_b, const void* w_t, void* dx, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* 3x3x3 stride-1 pad-1 convolution as implicit GEMM                         */
+/* (swin_unetr.py:87,229-237,260-266; unet_blocks.py:46-56,74)              */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpConvDesc {
+    int32_t B;
+    int32_t dims[3];            /* H, W, D (same for input and output)                 */
+    int32_t Cin;                /* multiple of 8                                       */
+    int32_t Cout;               /* real output channels                                */
+    int32_t Kp;                 /* 27*Cin rounded up to 32 = row length of w           */
+    int32_t pro_affine;         /* 1: x' = x*scale[ci] + shift[ci] on in-bounds voxels */
+    int32_t pro_lrelu;          /* 1: then LeakyReLU(0.01)                             */
+    int32_t add_residual;       /* 1: y += residual (bf16, same shape as y)            */
+    int32_t out_f32;            /* 1: y is fp32 [B,vol,Cout], else bf16                */
+} MivpConvDesc;
+/* x [B,H,W,D,Cin] bf16 ; w [Cout_p][Kp] bf16 with k = tap*Cin + ci, tap = (kh*3+kw)*3+kd,
+ * rows >= Cout and columns >= 27*Cin zero (Cout_p = Cout rounded up to 16) ; bias [Cout] f32 or NULL */
+int mivp_conv3d_fwd(const MivpConvDesc* d, const void* x, const void* w, const float* bias,
+                    const float* scale, const float* shift, const void* residual, void* y,
+                    mivp_stream_t stream);
+/* weight gradient for small Cout (segmentation heads):
+ *   dw [Cout][27][Cin] f32 += sum_v dy[v][co] * x'[v+tap][ci] ; db [Cout] f32
+ *   dy [B,vol,Cp] bf16 with Cp channels per voxel (>= Cout) ; partial sums land in part[] and are
+ *   reduced deterministically; part needs mivp_conv3d_wgrad_small_ws(d) floats                  */
+size_t mivp_conv3d_wgrad_small_ws(const MivpConvDesc* d);
+int mivp_conv3d_wgrad_small(const MivpConvDesc* d, const void* x, const float* scale, const float* shift,
+                            const void* dy, int32_t dy_stride, float* part, float* dw, float* db,
+                            mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Patch embedding + BatchNorm statistics (swin_unetr.py:148-158)            */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpEmbedDesc {
+    int32_t B, Cin;
+    int32_t dims[3];            /* input H, W, D (fp32, channels-first [B,Cin,H,W,D])  */
+    int32_t C;                  /* output channels, multiple of 8                      */
+    int32_t nblk;               /* stats blocks: rows of `part`                        */
+} MivpEmbedDesc;
+/* mode 0: accumulate per-channel sum / sum-of-squares of conv(x)+bias into part [nblk][2C] f32
+ * mode 1: y = (conv(x)+bias) * scale + shift -> bf16 [B,h,w,d,C]                        */
+int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x, const float* w, const float* bias,
+                     const float* scale, const float* shift, float* part, void* y, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* BatchNorm3d, training mode (batch statistics), channels-last bf16         */
+/* ------------------------------------------------------------------------ */
+/* per-channel partial sums of a bf16 [n_vox][C] tensor -> part [nblk][2C] f32 */
+int mivp_bn_stats(const void* x, int64_t n_vox, int32_t C, int32_t nblk, float* part, mivp_stream_t stream);
+/* part -> mean/rstd -> scale = w*rstd, shift = b - mean*scale ; running stats updated in place
+ * (momentum, unbiased variance) ; mean_rstd [2C] f32 saved for backward                 */
+int mivp_bn_finalize(const float* part, int32_t nblk, int32_t C, double count, const float* w, const float* b,
+                     float eps, float momentum, float* running_mean, float* running_var,
+                     float* scale, float* shift, float* mean_rstd, mivp_stream_t stream);
+/* y = act(x*scale + shift), bf16 -> bf16 (used where the consumer cannot fuse the affine) */
+int mivp_affine_act(const void* x, int64_t n_vox, int32_t C, const float* scale, const float* shift,
+                    int32_t lrelu, void* y, mivp_stream_t stream);
+/* backward reductions: part [nblk][2C] : sum(dy), sum(dy * xhat) over voxels, where
+ * dy is taken AFTER the activation derivative when lrelu=1 (z = x*scale+shift, dy *= z>0 ? 1 : 0.01) */
+int mivp_bn_bwd_stats(const void* x, const void* dy, int64_t n_vox, int32_t C, const float* scale,
+                      const float* shift, const float* mean_rstd, int32_t lrelu, int32_t nblk, float* part,
+                      mivp_stream_t stream);
+/* dx = scale * (dyz - sum_dy/n - xhat * sum_dy_xhat/n) ; sums [2C] f32 (already reduced) */
+int mivp_bn_bwd_apply(const void* x, const void* dy, int64_t n_vox, int32_t C, const float* scale,
+                      const float* shift, const float* mean_rstd, const float* sums, int32_t lrelu,
+                      void* dx, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Trilinear upsample (align_corners=False) + crop + concat                  */
+/* (unet_blocks.py:31-35,72-73; swin_unetr.py:351-355)                       */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpUpcatDesc {
+    int32_t B;
+    int32_t idims[3];           /* low-res input dims                                  */
+    int32_t odims[3];           /* output dims (= skip dims; <= scale*idims)            */
+    int32_t scale[3];           /* 1 or 2 per axis                                     */
+    int32_t Cx;                 /* channels of the low-res tensor                      */
+    int32_t Cs;                 /* channels of the skip tensor (0 = no concat)         */
+} MivpUpcatDesc;
+/* x [B,ih,iw,id,Cx] bf16, skip [B,oh,ow,od,Cs] bf16 -> y [B,oh,ow,od,Cx+Cs] bf16 */
+int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void* y, mivp_stream_t stream);
+/* dy [B,oh,ow,od,Cx+Cs] bf16 -> dx [B,ih,iw,id,Cx] bf16 (transposed stencil), dskip (slice copy; may be NULL) */
+int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* small utilities                                                          */
+/* ------------------------------------------------------------------------ */
+/* fp32 -> bf16 cast of n elements (weight staging) */
+int mivp_cast_f32_bf16(const float* in, int64_t n, void* out, mivp_stream_t stream);
+/* y = a + b (bf16, n elements) : gradient accumulation at skip joins */
+int mivp_add_bf16(const void* a, const void* b, int64_t n, void* y, mivp_stream_t stream);
+/* MFMA lane-map self test: c[16][16] f32 = a[16][32] * b[16][32]^T via one 16x16x32 MFMA */
+int mivp_selftest_mfma(const void* a, const void* b, float* c, mivp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIVP_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libmivp_hip.so (the C ABI declared in include/mivp.h).
+
+The product path has NO fallback: if the library is missing or a call fails,
+a RuntimeError is raised.  Tensors are passed as raw device pointers
+(``tensor.data_ptr()``) plus the current torch HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
+ABI_VERSION = 1
+
+i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
+
+
+class SwinDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "C", "heads", "vol_in", "vol_out", "P", "Nq", "Nqp", "Np", "Npp", "Nkp",
+                                   "aug", "augp", "has_mask")] + [("win", i32 * 3), ("q_scale", f32), ("ln_eps", f32)]
+
+
+class MergeDesc(C.Structure):
+    _fields_ = [("B", i32), ("C", i32), ("dims", i32 * 3), ("odims", i32 * 3), ("merge_last", i32), ("Cout", i32),
+                ("ln_eps", f32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", i32), ("dims", i32 * 3), ("Cin", i32), ("Cout", i32), ("Kp", i32), ("pro_affine", i32),
+                ("pro_lrelu", i32), ("add_residual", i32), ("out_f32", i32)]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("B", i32), ("Cin", i32), ("dims", i32 * 3), ("C", i32), ("nblk", i32)]
+
+
+class UpcatDesc(C.Structure):
+    _fields_ = [("B", i32), ("idims", i32 * 3), ("odims", i32 * 3), ("scale", i32 * 3), ("Cx", i32), ("Cs", i32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"mivp_amd: {LIB_PATH} is missing. Build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mivp_last_error.restype = C.c_char_p
+        if hasattr(_lib, "mivp_conv3d_wgrad_small_ws"):
+            _lib.mivp_conv3d_wgrad_small_ws.restype = C.c_size_t
+        ver = _lib.mivp_abi_version()
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"mivp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")
+    return _lib
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_contiguous():
+        raise RuntimeError("mivp_amd: non-contiguous tensor passed to the C ABI")
+    if not t.is_cuda:
+        raise RuntimeError("mivp_amd: the HIP kernels need device tensors (no CPU fallback; the CPU oracle "
+                           "lives in oracle/ and is test infrastructure only)")
+    return C.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError(f"mivp_amd: {name} failed with code {rc}: {lib().mivp_last_error().decode()}")

@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  Wave = 64 lanes.
+//
+// MFMA convention used everywhere ("swapped" orientation):
+//   acc = mfma_f32_16x16x32_bf16(A, B, acc)   with  D[row][col] += sum_k A[row][k] * B[k][col]
+//   lane l: r = l & 15, g = l >> 4
+//     A operand: 8 bf16 = A[row r][k = 8g .. 8g+7]
+//     B operand: 8 bf16 = B[k = 8g .. 8g+7][col r]
+//     D        : 4 f32  = D[row 4g + j][col r], j = 0..3
+//   We always put the WEIGHT tile on A (rows = output channels) and the TOKEN tile on B
+//   (cols = tokens), so that after the MFMA every lane owns ONE token (r) and four
+//   consecutive output channels (4g..4g+3): epilogues are 8-byte stores and per-token
+//   reductions (LayerNorm, softmax) need only two cross-lane steps (xor 16, xor 32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mivp.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MIVP_DEV __device__ __forceinline__
+
+MIVP_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+MIVP_DEV bf16x8 zero8() { bf16x8 z; for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f; return z; }
+MIVP_DEV bf16x4 zero4() { bf16x4 z; for (int i = 0; i < 4; ++i) z[i] = (bf16_t)0.0f; return z; }
+MIVP_DEV f32x4 fzero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+MIVP_DEV bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+MIVP_DEV bf16x4 ld4(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+MIVP_DEV void st8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+MIVP_DEV void st4(bf16_t* p, bf16x4 v) { *reinterpret_cast<bf16x4*>(p) = v; }
+
+MIVP_DEV bf16x4 pack4(f32x4 v) {
+    bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; return o;
+}
+MIVP_DEV bf16x8 cat44(bf16x4 lo, bf16x4 hi) {
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+// sum / max over the 4 lanes that share a token column (lanes r, r+16, r+32, r+48)
+MIVP_DEV float col_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+MIVP_DEV float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v; }
+
+// error plumbing shared by the C-ABI translation units
+void mivp_set_error(const char* msg);
+int mivp_check_launch(const char* what);
+
+#define MIVP_REQUIRE(cond) do { if (!(cond)) { mivp_set_error("contract violated: " #cond); return MIVP_EINVAL; } } while (0)

@@ -1,0 +1,608 @@
+// Swin block forward: gather+LN+QKV, prompt K/V, bias augmentation, window attention,
+// proj+MLP+scatter.  Reference semantics: swin_transformer/swin_block.py:145-255,
+// multi_head_attention/window_attention.py:35-61, relative_positional_encoding.py:99-142.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// K1a  gather + LayerNorm + QKV
+//   one wave = 32 tokens (two 16-token B tiles) so that every weight fragment fetched from L2
+//   feeds two MFMAs; no LDS: the B operand (tokens) is loaded straight into its MFMA lane map
+//   (lane r,g holds 8 consecutive channels of token r), LayerNorm statistics are per-lane
+//   partials + two xor-shuffles.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16_t* __restrict__ x,
+                                                      const int* __restrict__ tok_src,
+                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                      const bf16_t* __restrict__ wqkv,
+                                                      bf16_t* __restrict__ q, bf16_t* __restrict__ k,
+                                                      bf16_t* __restrict__ v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, hd = C / d.heads;
+    const long T = (long)d.B * d.P * d.Nqp;
+    const long tile0 = ((long)blockIdx.x * 4 + wave) * 2;
+
+    bf16x8 xb[2][KS];
+    long bp[2];
+    int slot[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long t = (tile0 + u) * 16 + r;
+        live[u] = t < T;
+        const long tt = live[u] ? t : 0;
+        bp[u] = tt / d.Nqp;
+        slot[u] = (int)(tt - bp[u] * d.Nqp);
+        const int pw = (int)(bp[u] % d.P);
+        const long b = bp[u] / d.P;
+        const int src = live[u] ? tok_src[pw * d.Nqp + slot[u]] : -2;
+        float xs[KS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            if (src >= 0 && c < C) {
+                bf16x8 raw = ld8(x + ((b * d.vol_in + src) * (long)C + c));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { xs[s][i] = (float)raw[i]; sum += xs[s][i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs[s][i] = 0.f;
+            }
+        }
+        const float mean = col_sum(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (32 * s + 8 * g < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float dv = xs[s][i] - mean; var += dv * dv; }
+            }
+        }
+        const float rstd = rsqrtf(col_sum(var) / (float)C + d.ln_eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 y = zero8();
+            if (src >= -1 && c < C) {          // -1: zero-pad token still goes through LN (-> beta)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = (bf16_t)((xs[s][i] - mean) * rstd * ln_w[c + i] + ln_b[c + i]);
+            }
+            xb[u][s] = y;
+        }
+    }
+
+    const int n_out = 3 * C;
+    const int n_tiles = (n_out + 15) / 16;
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        f32x4 acc0 = fzero4(), acc1 = fzero4();
+        const int nrow = 16 * nt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (nrow < n_out && c < C) a = ld8(wqkv + (long)nrow * C + c);
+            acc0 = mfma16(a, xb[0][s], acc0);
+            acc1 = mfma16(a, xb[1][s], acc1);
+        }
+        const int n0 = 16 * nt + 4 * g;
+        if (n0 < n_out) {
+            const int sel = n0 / C;
+            const int cc = n0 - sel * C;
+            const int head = cc / hd;
+            const int j0 = cc - head * hd;
+            bf16_t* base = sel == 0 ? q : (sel == 1 ? k : v);
+            const float sc = sel == 0 ? d.q_scale : 1.0f;
+            if (live[0]) st4(base + ((bp[0] * d.heads + head) * d.Nqp + slot[0]) * (long)hd + j0, pack4(acc0 * sc));
+            if (live[1]) st4(base + ((bp[1] * d.heads + head) * d.Nqp + slot[1]) * (long)hd + j0, pack4(acc1 * sc));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  prompt tokens -> LN -> K_p, V_p (once per block; 64 rows: plain VALU)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prompt_kv_fwd(MivpSwinDesc d, const float* __restrict__ prompt,
+                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                       const bf16_t* __restrict__ wqkv, bf16_t* __restrict__ kp,
+                                                       bf16_t* __restrict__ vp, float* __restrict__ yln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* y = reinterpret_cast<float*>(smem);             // [C]
+    float* red = y + d.C;                                   // [8]
+    const int t = blockIdx.x, C = d.C, hd = C / d.heads;
+    const int tid = threadIdx.x;
+    if (t >= d.Np) {                                        // zero the padding rows
+        for (int n = tid; n < 2 * C; n += 256) {
+            const int sel = n / C, cc = n - sel * C, head = cc / hd, j = cc - head * hd;
+            (sel == 0 ? kp : vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)0.0f;
+        }
+        return;
+    }
+    float part = 0.f;
+    for (int c = tid; c < C; c += 256) part += prompt[(long)t * C + c];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    __syncthreads();
+    part = 0.f;
+    for (int c = tid; c < C; c += 256) { const float dv = prompt[(long)t * C + c] - mean; part += dv * dv; }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = part;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + d.ln_eps);
+    for (int c = tid; c < C; c += 256) {
+        const float yy = (prompt[(long)t * C + c] - mean) * rstd * ln_w[c] + ln_b[c];
+        if (yln) yln[(long)t * C + c] = yy;
+        y[c] = (float)(bf16_t)yy;                           // same rounding point as the window tokens
+    }
+    __syncthreads();
+    for (int n = tid; n < 2 * C; n += 256) {
+        const int sel = n / C, cc = n - sel * C;
+        const bf16_t* wrow = wqkv + (long)((sel + 1) * C + cc) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += y[c] * (float)wrow[c];
+        const int head = cc / hd, j = cc - head * hd;
+        (sel == 0 ? kp : vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  relative-position bias -> augmentation columns of Q' / K'
+//   bias[n,m] = Th[k0-i0+w0-1] + Tw[k1-i1+w1-1] + Td[k2-i2+w2-1]   (tables pre-scaled by s/3)
+//   query side: one-hot(i0) | one-hot(i1) | one-hot(i2) without its last entry
+//   key side  : Th[.. for each i0] + c | Tw[..] | Td[..] - Td_last,  c = Td at i2 = w2-1
+//   prompt key t: ts[t] in every i0 column (the i0 one-hot sums to one).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float* __restrict__ t_h,
+                                                     const float* __restrict__ t_w, const float* __restrict__ t_d,
+                                                     const float* __restrict__ ts, bf16_t* __restrict__ qa,
+                                                     bf16_t* __restrict__ ka) {
+    const int head = blockIdx.x;
+    const int w0 = d.win[0], w1 = d.win[1], w2 = d.win[2];
+    const int A = d.augp;
+    if (head == 0) {
+        for (int e = threadIdx.x; e < d.Nqp * A; e += 256) {
+            const int n = e / A, a = e - n * A;
+            float val = 0.f;
+            if (n < d.Nq) {
+                const int i2 = n % w2, i1 = (n / w2) % w1, i0 = n / (w2 * w1);
+                if (a < w0) val = (a == i0) ? 1.f : 0.f;
+                else if (a < w0 + w1) val = (a - w0 == i1) ? 1.f : 0.f;
+                else if (a < w0 + w1 + w2 - 1) val = (a - w0 - w1 == i2) ? 1.f : 0.f;
+            }
+            qa[e] = (bf16_t)val;
+        }
+    }
+    const float* th = t_h + (long)head * (2 * w0 - 1);
+    const float* tw = t_w + (long)head * (2 * w1 - 1);
+    const float* td = t_d + (long)head * (2 * w2 - 1);
+    for (int e = threadIdx.x; e < d.Nkp * A; e += 256) {
+        const int m = e / A, a = e - m * A;
+        float val = 0.f;
+        if (m < d.Nq) {
+            const int k2 = m % w2, k1 = (m / w2) % w1, k0 = m / (w2 * w1);
+            const float fold = td[k2 - (w2 - 1) + w2 - 1];          // query i2 = w2-1
+            if (a < w0) val = th[k0 - a + w0 - 1] + fold;
+            else if (a < w0 + w1) val = tw[k1 - (a - w0) + w1 - 1];
+            else if (a < w0 + w1 + w2 - 1) val = td[k2 - (a - w0 - w1) + w2 - 1] - fold;
+        } else if (m >= d.Nqp && m < d.Nqp + d.Np) {
+            if (a < w0) val = ts[(long)head * d.Np + (m - d.Nqp)];
+        }
+        ka[((long)head * d.Nkp + m) * A + a] = (bf16_t)val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b  window attention forward, one workgroup per (window instance, head)
+//   LDS: K' image [Nkp][DK+8], Q' image [Nqp][DK+8] (rows = head dims | bias aug | zero pad),
+//        V^T image [16*DVT][Nkp+8], key region ids.
+//   Each wave walks 16-query tiles; S^T = K' Q'^T puts ONE query on each lane, so the softmax
+//   row reductions are in-lane + 2 shuffles and P feeds the PV MFMA with no lane movement
+//   (k index permuted identically on both operands).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int DKS, int DVT>
+__global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+                                                      const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                      const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
+                                                      const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
+                                                      const int* __restrict__ tok_rid, bf16_t* __restrict__ o,
+                                                      float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DK = 32 * DKS;
+    constexpr int KROW = (DK + 8) * 2;                       // bytes
+    const int Nkp = d.Nkp, Nqp = d.Nqp;
+    const int VROW = (Nkp + 8) * 2;                          // bytes
+    char* Kimg = smem;
+    char* Qimg = Kimg + (size_t)Nkp * KROW;
+    char* Vt = Qimg + (size_t)Nqp * KROW;
+    int* ridk = reinterpret_cast<int*>(Vt + (size_t)(16 * DVT) * VROW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, heads = d.heads, hd = C / heads;
+    const long bph = blockIdx.x;                             // (b*P + pw)*heads + head
+    const int head = (int)(bph % heads);
+    const long bp = bph / heads;
+    const int pw = (int)(bp % d.P);
+    const int A = d.augp;
+    const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4;
+
+    // ---- stage K' ----
+    for (int e = tid; e < Nkp * dk4; e += 256) {
+        const int row = e / dk4, c4 = e - row * dk4;
+        bf16x4 val = zero4();
+        if (c4 < hd4) {
+            if (row < Nqp) val = ld4(k + ((bph * Nqp + row) * (long)hd + 4 * c4));
+            else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+        } else if (c4 < hd4 + a4) {
+            val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
+        }
+        *reinterpret_cast<bf16x4*>(Kimg + (size_t)row * KROW + 8 * c4) = val;
+    }
+    // ---- stage Q' ----
+    for (int e = tid; e < Nqp * dk4; e += 256) {
+        const int row = e / dk4, c4 = e - row * dk4;
+        bf16x4 val = zero4();
+        if (c4 < hd4) val = ld4(q + ((bph * Nqp + row) * (long)hd + 4 * c4));
+        else if (c4 < hd4 + a4) val = ld4(qa + ((long)row * A + 4 * (c4 - hd4)));
+        *reinterpret_cast<bf16x4*>(Qimg + (size_t)row * KROW + 8 * c4) = val;
+    }
+    // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows) ----
+    for (int e = tid; e < Nkp * (4 * DVT); e += 256) {
+        const int row = e / (4 * DVT), c4 = e - row * (4 * DVT);
+        bf16x4 val = zero4();
+        if (c4 < hd4) {
+            if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
+            else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<bf16_t*>(Vt + (size_t)(4 * c4 + i) * VROW + 2 * row) = val[i];
+    }
+    // ---- key classes: -1 excluded, -2 always attended (prompt), else region id ----
+    for (int m = tid; m < Nkp; m += 256) {
+        int cls = -1;
+        if (m < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + m] : 0;
+        else if (m >= Nqp && m < Nqp + d.Np) cls = -2;
+        ridk[m] = cls;
+    }
+    __syncthreads();
+
+    // NT = Nkp / 16 key tiles (even), a template parameter so every S tile lives in fixed registers
+    const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
+    const float LOG2E = 1.4426950408889634f;
+
+    for (int qt = wave; qt < Nqp / 16; qt += 4) {
+        const int qrow = qt * 16 + r;
+        const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        bf16x8 qf[DKS];
+#pragma unroll
+        for (int s = 0; s < DKS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qimg + (size_t)qrow * KROW + (32 * s + 8 * g) * 2);
+
+        f32x4 S[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            {
+                f32x4 acc = fzero4();
+#pragma unroll
+                for (int s = 0; s < DKS; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * t + r) * KROW + (32 * s + 8 * g) * 2);
+                    acc = mfma16(a, qf[s], acc);
+                }
+                if (t < nt_full) {
+                    if (d.has_mask) {
+                        const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
+                        acc[0] = (kr.x == rq) ? acc[0] : 0.f;
+                        acc[1] = (kr.y == rq) ? acc[1] : 0.f;
+                        acc[2] = (kr.z == rq) ? acc[2] : 0.f;
+                        acc[3] = (kr.w == rq) ? acc[3] : 0.f;
+                    }
+                } else {
+                    const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
+                    const int krs[4] = {kr.x, kr.y, kr.z, kr.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (krs[j] == -1) acc[j] = -INFINITY;
+                        else if (krs[j] != -2 && krs[j] != rq) acc[j] = 0.f;
+                    }
+                }
+                S[t] = acc;
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+            }
+        }
+        mx = col_max(mx);
+        const float mb = mx * LOG2E;
+        float lsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(S[t][j] * LOG2E - mb);
+                    S[t][j] = p;
+                    lsum += p;
+                }
+            }
+        }
+        lsum = col_sum(lsum);
+
+        f32x4 oacc[DVT];
+#pragma unroll
+        for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+            {
+                const bf16x8 pb = cat44(pack4(S[2 * u]), pack4(S[2 * u + 1]));
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) {
+                    const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
+                    const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
+                                           *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
+                    oacc[dd] = mfma16(a, pb, oacc[dd]);
+                }
+            }
+        }
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int dd = 0; dd < DVT; ++dd) {
+            const int j0 = 16 * dd + 4 * g;
+            if (j0 < hd) st4(o + ((bp * Nqp + qrow) * (long)C + head * hd + j0), pack4(oacc[dd] * inv));
+        }
+        if (g == 0) lse[bph * Nqp + qrow] = mx + logf(lsum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1c  proj + residual -> LayerNorm -> Linear + residual -> scatter/crop
+//   two chained GEMMs per token without LDS: the accumulator of GEMM1 (lane r,g owns channels
+//   16*t+4g..+3 of token r) becomes the B operand of GEMM2 by pairing tiles (2s, 2s+1) into one
+//   32-deep k-step and reading the weight row in the same permuted k order.
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const bf16_t* __restrict__ o,
+                                                           const bf16_t* __restrict__ x,
+                                                           const int* __restrict__ tok_src, const int* __restrict__ tok_dst,
+                                                           const bf16_t* __restrict__ wproj, const float* __restrict__ bproj,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                           const bf16_t* __restrict__ wmlp, const float* __restrict__ bmlp,
+                                                           bf16_t* __restrict__ t1_out, bf16_t* __restrict__ y) {
+    constexpr int KS = (CT + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C;
+    const long T = (long)d.B * d.P * d.Nqp;
+    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
+    const bool live = t < T;
+    const long tt = live ? t : 0;
+    const long bp = tt / d.Nqp;
+    const int slot = (int)(tt - bp * d.Nqp);
+    const int pw = (int)(bp % d.P);
+    const long b = bp / d.P;
+    const int src = live ? tok_src[pw * d.Nqp + slot] : -2;
+    const int dst = live ? tok_dst[pw * d.Nqp + slot] : -1;
+
+    bf16x8 ob[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+        ob[s] = (live && c < C) ? ld8(o + (tt * (long)C + c)) : zero8();
+    }
+    // GEMM1: t1 = o Wproj^T + b + shortcut
+    f32x4 t1[CT];
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+        f32x4 acc = fzero4();
+        const int nrow = 16 * nt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (nrow < C && c < C) a = ld8(wproj + (long)nrow * C + c);
+            acc = mfma16(a, ob[s], acc);
+        }
+        const int n0 = 16 * nt + 4 * g;
+        if (n0 < C) {
+            f32x4 sc = fzero4();
+            if (src >= 0) { bf16x4 xv = ld4(x + ((b * d.vol_in + src) * (long)C + n0)); for (int j = 0; j < 4; ++j) sc[j] = (float)xv[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float val = (float)(bf16_t)(acc[j] + bproj[n0 + j] + sc[j]);   // t1 lives as bf16
+                acc[j] = val;
+                sum += val;
+            }
+            if (t1_out && live) st4(t1_out + (tt * (long)C + n0), pack4(acc));
+        } else {
+            acc = fzero4();
+        }
+        t1[nt] = acc;
+    }
+    const float mean = col_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+        if (16 * nt + 4 * g < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dv = t1[nt][j] - mean; var += dv * dv; }
+        }
+    }
+    const float rstd = rsqrtf(col_sum(var) / (float)C + d.ln_eps);
+    bf16x4 y2[2 * KS];
+#pragma unroll
+    for (int nt = 0; nt < 2 * KS; ++nt) {
+        bf16x4 yy = zero4();
+        if (nt < CT) {
+            const int n0 = 16 * nt + 4 * g;
+            if (n0 < C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yy[j] = (bf16_t)((t1[nt][j] - mean) * rstd * ln_w[n0 + j] + ln_b[n0 + j]);
+            }
+        }
+        y2[nt] = yy;
+    }
+    // GEMM2: t2 = t1 + y2 Wmlp^T + b ; k-step s covers channels 32s..32s+31 in the order
+    // kappa = 8g+j' -> channel 32s + 16*(j'>>2) + 4g + (j'&3)
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt) {
+        f32x4 acc = fzero4();
+        const int nrow = 16 * mt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x4 lo = zero4(), hi = zero4();
+            const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
+            if (nrow < C) {
+                if (c0 < C) lo = ld4(wmlp + (long)nrow * C + c0);
+                if (c1 < C) hi = ld4(wmlp + (long)nrow * C + c1);
+            }
+            acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
+        }
+        const int n0 = 16 * mt + 4 * g;
+        if (n0 < C && dst >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += t1[mt][j] + bmlp[n0 + j];
+            st4(y + ((b * d.vol_out + dst) * (long)C + n0), pack4(acc));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int swin_common_checks(const MivpSwinDesc* d) {
+    MIVP_REQUIRE(d != nullptr);
+    MIVP_REQUIRE(d->B > 0 && d->C > 0 && d->heads > 0 && d->P > 0);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->C % d->heads == 0 && (d->C / d->heads) % 4 == 0);
+    MIVP_REQUIRE(d->Nqp % 16 == 0 && d->Nqp >= d->Nq && d->Nqp - d->Nq < 16);
+    MIVP_REQUIRE(d->Npp % 16 == 0 && d->Npp >= d->Np);
+    MIVP_REQUIRE(d->Nkp % 32 == 0 && d->Nkp >= d->Nqp + d->Npp);
+    MIVP_REQUIRE(d->augp % 4 == 0 && d->augp >= d->aug);
+    MIVP_REQUIRE(d->aug == d->win[0] + d->win[1] + d->win[2] - 1);
+    MIVP_REQUIRE(d->Nq == d->win[0] * d->win[1] * d->win[2]);
+    return MIVP_OK;
+}
+
+extern "C" int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_src, const float* ln_w,
+                                 const float* ln_b, const void* wqkv, void* q, void* k, void* v,
+                                 mivp_stream_t stream) {
+    int rc = swin_common_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(x && tok_src && ln_w && ln_b && wqkv && q && k && v);
+    const long T = (long)d->B * d->P * d->Nqp;
+    const unsigned grid = (unsigned)((T + 127) / 128);
+    const int KS = (d->C + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_QKV(K) hipLaunchKernelGGL((k_swin_qkv_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)x, tok_src, \
+                                          ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v)
+    switch (KS) {
+        case 1: LAUNCH_QKV(1); break;
+        case 2: LAUNCH_QKV(2); break;
+        case 3: LAUNCH_QKV(3); break;
+        case 4: LAUNCH_QKV(4); break;
+        case 6: LAUNCH_QKV(6); break;
+        default: mivp_set_error("swin_qkv_fwd: C/32 not in {1,2,3,4,6}"); return MIVP_EUNSUPPORTED;
+    }
+#undef LAUNCH_QKV
+    return mivp_check_launch("swin_qkv_fwd");
+}
+
+extern "C" int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* ln_w, const float* ln_b,
+                                  const void* wqkv, void* kp, void* vp, float* yln, mivp_stream_t stream) {
+    int rc = swin_common_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(d->Np > 0 && prompt && ln_w && ln_b && wqkv && kp && vp);
+    hipLaunchKernelGGL(k_prompt_kv_fwd, dim3(d->Npp), dim3(256), (d->C + 8) * sizeof(float), (hipStream_t)stream, *d,
+                       prompt, ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)kp, (bf16_t*)vp, yln);
+    return mivp_check_launch("prompt_kv_fwd");
+}
+
+extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, const float* t_d,
+                                const float* ts, void* qa, void* ka, mivp_stream_t stream) {
+    int rc = swin_common_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(t_h && t_w && t_d && qa && ka);
+    MIVP_REQUIRE(d->Np == 0 || ts != nullptr);
+    hipLaunchKernelGGL(k_relbias_aug, dim3(d->heads), dim3(256), 0, (hipStream_t)stream, *d, t_h, t_w, t_d, ts,
+                       (bf16_t*)qa, (bf16_t*)ka);
+    return mivp_check_launch("relbias_aug");
+}
+
+template <int NT, int DKS, int DVT>
+static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                           const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
+                           hipStream_t st) {
+    const size_t krow = (32 * DKS + 8) * 2, vrow = (d->Nkp + 8) * 2;
+    const size_t lds = (size_t)d->Nkp * krow + (size_t)d->Nqp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
+    if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
+    auto kern = k_win_attn_fwd<NT, DKS, DVT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
+    }
+    const unsigned grid = (unsigned)((long)d->B * d->P * d->heads);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse);
+    return mivp_check_launch("win_attn_fwd");
+}
+
+// shared by forward and backward dispatch: which (NT, DKS=DVT) instantiation covers this shape
+int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt) {
+    const int hd = d->C / d->heads;
+    const int dk = hd + d->augp;
+    int ks = (dk + 31) / 32;
+    const int vt = (hd + 15) / 16;
+    if (vt > ks) ks = vt;                   // instantiations are diagonal: (1,1) (2,2) (3,3)
+    *dks = ks;
+    *nt = d->Nkp / 16;
+    if (ks > 3) return MIVP_EUNSUPPORTED;
+    switch (*nt) { case 2: case 4: case 16: case 20: case 22: case 26: return MIVP_OK; default: return MIVP_EUNSUPPORTED; }
+}
+
+extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                                 const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o,
+                                 float* lse, mivp_stream_t stream) {
+    int rc = swin_common_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(q && k && v && qa && ka && o && lse);
+    MIVP_REQUIRE(d->Np == 0 || (kp && vp));
+    MIVP_REQUIRE(!d->has_mask || tok_rid);
+    int dks, nt;
+    if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_fwd: head_dim / key count outside the instantiated set"); return MIVP_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+#define ATT(N, K) return launch_attn_fwd<N, K, K>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st)
+#define ATTN(N) if (nt == N) { if (dks == 1) ATT(N, 1); if (dks == 2) ATT(N, 2); ATT(N, 3); }
+    ATTN(2) ATTN(4) ATTN(16) ATTN(20) ATTN(22) ATTN(26)
+#undef ATTN
+#undef ATT
+    return MIVP_EUNSUPPORTED;
+}
+
+extern "C" int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x, const int32_t* tok_src,
+                                      const int32_t* tok_dst, const void* wproj, const float* bproj, const float* ln_w,
+                                      const float* ln_b, const void* wmlp, const float* bmlp, void* t1, void* y,
+                                      mivp_stream_t stream) {
+    int rc = swin_common_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(o && x && tok_src && tok_dst && wproj && bproj && ln_w && ln_b && wmlp && bmlp && y);
+    const long T = (long)d->B * d->P * d->Nqp;
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    const int CT = (d->C + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PM(K) hipLaunchKernelGGL((k_swin_proj_mlp_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)o, \
+                                         (const bf16_t*)x, tok_src, tok_dst, (const bf16_t*)wproj, bproj, ln_w, ln_b,   \
+                                         (const bf16_t*)wmlp, bmlp, (bf16_t*)t1, (bf16_t*)y)
+    switch (CT) {
+        case 1: LAUNCH_PM(1); break;
+        case 2: LAUNCH_PM(2); break;
+        case 3: LAUNCH_PM(3); break;
+        case 4: LAUNCH_PM(4); break;
+        case 6: LAUNCH_PM(6); break;
+        case 8: LAUNCH_PM(8); break;
+        case 12: LAUNCH_PM(12); break;
+        default: mivp_set_error("swin_proj_mlp_fwd: C/16 not in {1,2,3,4,6,8,12}"); return MIVP_EUNSUPPORTED;
+    }
+#undef LAUNCH_PM
+    return mivp_check_launch("swin_proj_mlp_fwd");
+}

@@ -1,0 +1,96 @@
+// Error plumbing, tiny utilities and the MFMA lane-map self test.
+#include "common.hpp"
+#include <string.h>
+
+static thread_local char g_err[256] = "ok";
+
+void mivp_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "unknown", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+
+int mivp_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        mivp_set_error(buf);
+        return MIVP_ELAUNCH;
+    }
+    return MIVP_OK;
+}
+
+extern "C" int mivp_abi_version(void) { return 1; }
+extern "C" const char* mivp_last_error(void) { return g_err; }
+
+__global__ void k_cast_f32_bf16(const float* __restrict__ in, long n, bf16_t* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (bf16_t)in[i];
+}
+
+extern "C" int mivp_cast_f32_bf16(const float* in, int64_t n, void* out, mivp_stream_t stream) {
+    MIVP_REQUIRE(in && out && n >= 0);
+    if (n == 0) return MIVP_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (long)n, (bf16_t*)out);
+    return mivp_check_launch("cast_f32_bf16");
+}
+
+__global__ void k_add_bf16(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long n8, bf16_t* __restrict__ y) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        bf16x8 va = ld8(a + 8 * i), vb = ld8(b + 8 * i), vo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vo[j] = (bf16_t)((float)va[j] + (float)vb[j]);
+        st8(y + 8 * i, vo);
+    }
+}
+
+extern "C" int mivp_add_bf16(const void* a, const void* b, int64_t n, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(a && b && y && n >= 0 && n % 8 == 0);
+    if (n == 0) return MIVP_OK;
+    const long n8 = n / 8;
+    const unsigned grid = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    hipLaunchKernelGGL(k_add_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, n8,
+                       (bf16_t*)y);
+    return mivp_check_launch("add_bf16");
+}
+
+// out[r] = sum_i in[i*rows + r]; one thread per r walks i in a fixed order -> deterministic
+__global__ void k_reduce_rows(const float* __restrict__ in, long n, long rows, float* __restrict__ out) {
+    const long rr = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr >= rows) return;
+    float acc = 0.f, comp = 0.f;                 // Kahan: n can be thousands of windows
+    for (long i = 0; i < n; ++i) {
+        const float yv = in[i * rows + rr] - comp;
+        const float tv = acc + yv;
+        comp = (tv - acc) - yv;
+        acc = tv;
+    }
+    out[rr] = acc;
+}
+
+extern "C" int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream) {
+    MIVP_REQUIRE(in && out && n >= 0 && rows > 0);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, in, (long)n,
+                       (long)rows, out);
+    return mivp_check_launch("reduce_rows");
+}
+
+// c[i][j] = sum_k a[i][k] * b[j][k]  (a, b: [16][32] bf16 row-major) through ONE MFMA with the lane
+// maps every other kernel in this library assumes.
+__global__ void k_selftest_mfma(const bf16_t* a, const bf16_t* b, float* c) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    bf16x8 fa = ld8(a + r * 32 + 8 * g);       // A[row r][k = 8g..]
+    bf16x8 fb = ld8(b + r * 32 + 8 * g);       // B[k = 8g..][col r] = b[r][k]
+    f32x4 acc = mfma16(fa, fb, fzero4());
+    for (int j = 0; j < 4; ++j) c[(4 * g + j) * 16 + r] = acc[j];
+}
+
+extern "C" int mivp_selftest_mfma(const void* a, const void* b, float* c, mivp_stream_t stream) {
+    MIVP_REQUIRE(a && b && c);
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, c);
+    return mivp_check_launch("selftest_mfma");
+}

@@ -1,0 +1,138 @@
+"""Host wrappers of the Swin-block kernels (K1-K3) around the C ABI.
+
+Mirrors ``SwinTransformerBlock.forward_attn_mlp`` (swin_transformer/swin_block.py:145-255):
+``swin_block_forward`` = gather+LN+QKV -> prompt K/V -> bias augmentation ->
+window attention -> proj+MLP+scatter, each one HIP launch.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .geometry import BlockTables, block_tables, round_up
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class SwinBlockWeights:
+    """Device-side, kernel-ready copies of one block's parameters."""
+    heads: int
+    ln1_w: torch.Tensor
+    ln1_b: torch.Tensor
+    wqkv: torch.Tensor          # bf16 [3C, C]
+    wproj: torch.Tensor         # bf16 [C, C]
+    bproj: torch.Tensor
+    ln2_w: torch.Tensor
+    ln2_b: torch.Tensor
+    wmlp: torch.Tensor          # bf16 [C, C]
+    bmlp: torch.Tensor
+    t_h: torch.Tensor           # f32 [heads, 2w-1], already * embed_dim**-0.5 / 3
+    t_w: torch.Tensor
+    t_d: torch.Tensor
+    ts: Optional[torch.Tensor]  # f32 [heads, Np], already * embed_dim**-0.5
+    wqkv_t: Optional[torch.Tensor] = None    # bf16 [C, 3C]   (backward)
+    wproj_t: Optional[torch.Tensor] = None   # bf16 [C, C]
+    wmlp_t: Optional[torch.Tensor] = None
+
+
+def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=False) -> SwinBlockWeights:
+    f = lambda k: sd[prefix + k].detach().to(device=device, dtype=torch.float32).contiguous()
+    scale = embed_dim ** -0.5
+    tabs = []
+    for name in "hwd":
+        tabs.append(((f(f"pe.weights_content_{name}") @ f(f"pe.enc_content_{name}").t()) * (scale / 3.0)).contiguous())
+    ts = None
+    if n_prompt:
+        ts = ((f("pe.weights_token") @ f("pe.enc_token.0").t())[:, :n_prompt] * scale).contiguous()
+    wqkv = torch.cat([f("attn.to_q.weight"), f("attn.to_k.weight"), f("attn.to_v.weight")], 0)
+    w = SwinBlockWeights(
+        heads=heads, ln1_w=f("attn_norm.weight"), ln1_b=f("attn_norm.bias"), wqkv=wqkv.to(BF16).contiguous(),
+        wproj=f("attn.proj.weight").to(BF16).contiguous(), bproj=f("attn.proj.bias"),
+        ln2_w=f("mlp_norm.weight"), ln2_b=f("mlp_norm.bias"), wmlp=f("mlp.weight").to(BF16).contiguous(),
+        bmlp=f("mlp.bias"), t_h=tabs[0], t_w=tabs[1], t_d=tabs[2], ts=ts)
+    if need_bwd:
+        w.wqkv_t = w.wqkv.t().contiguous()
+        w.wproj_t = w.wproj.t().contiguous()
+        w.wmlp_t = w.wmlp.t().contiguous()
+    return w
+
+
+def make_desc(B, C, heads, tb: BlockTables, n_prompt: int) -> L.SwinDesc:
+    d = L.SwinDesc()
+    d.B, d.C, d.heads = B, C, heads
+    d.vol_in = d.vol_out = tb.dims[0] * tb.dims[1] * tb.dims[2]
+    d.P, d.Nq, d.Nqp = tb.P, tb.Nq, tb.Nqp
+    d.Np = n_prompt
+    d.Npp = round_up(n_prompt, 16) if n_prompt else 0
+    d.Nkp = round_up(d.Nqp + d.Npp, 32)
+    w = tb.window
+    d.aug = w[0] + w[1] + w[2] - 1
+    d.augp = round_up(d.aug, 4)
+    d.has_mask = 1 if tb.has_mask else 0
+    for a in range(3):
+        d.win[a] = w[a]
+    d.q_scale = float((C // heads) ** -0.5)
+    d.ln_eps = 1e-6
+    return d
+
+
+@dataclass
+class SwinSaved:
+    desc: object
+    tb: BlockTables
+    x: torch.Tensor
+    q: torch.Tensor
+    k: torch.Tensor
+    v: torch.Tensor
+    kp: Optional[torch.Tensor]
+    vp: Optional[torch.Tensor]
+    qa: torch.Tensor
+    ka: torch.Tensor
+    o: torch.Tensor
+    lse: torch.Tensor
+    t1: torch.Tensor
+
+
+def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinBlockWeights, window, shift_cfg,
+                       save: bool = False):
+    """x: bf16 [B, H, W, D, C] channels-last; prompt: f32 [Np, C] or None.
+    Returns y (same shape) and, if ``save``, the tensors backward needs."""
+    if x.dtype != BF16 or x.dim() != 5:
+        raise RuntimeError("swin_block_forward expects a bf16 [B,H,W,D,C] tensor")
+    B, H, W_, D, Cc = x.shape
+    tb = block_tables((H, W_, D), tuple(int(v) for v in window), tuple(int(v) for v in shift_cfg), str(x.device))
+    n_prompt = 0 if prompt is None else int(prompt.shape[0])
+    d = make_desc(B, Cc, w.heads, tb, n_prompt)
+    hd = Cc // w.heads
+    dev = x.device
+    BP = B * tb.P
+    st = L.stream()
+    q = torch.empty((BP, w.heads, d.Nqp, hd), dtype=BF16, device=dev)
+    k = torch.empty_like(q)
+    v = torch.empty_like(q)
+    L.call("mivp_swin_qkv_fwd", C.byref(d), L.ptr(x), L.ptr(tb.tok_src), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
+           L.ptr(q), L.ptr(k), L.ptr(v), st)
+    kp = vp = None
+    if n_prompt:
+        kp = torch.empty((w.heads, d.Npp, hd), dtype=BF16, device=dev)
+        vp = torch.empty_like(kp)
+        pr = prompt.detach().to(torch.float32).contiguous()
+        L.call("mivp_prompt_kv_fwd", C.byref(d), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
+               L.ptr(kp), L.ptr(vp), L.ptr(None), st)
+    qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
+    ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
+    L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(w.ts), L.ptr(qa), L.ptr(ka), st)
+    o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
+    lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
+    L.call("mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp), L.ptr(qa), L.ptr(ka),
+           L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
+    t1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if save else None
+    y = torch.empty_like(x)
+    L.call("mivp_swin_proj_mlp_fwd", C.byref(d), L.ptr(o), L.ptr(x), L.ptr(tb.tok_src), L.ptr(tb.tok_dst), L.ptr(w.wproj),
+           L.ptr(w.bproj), L.ptr(w.ln2_w), L.ptr(w.ln2_b), L.ptr(w.wmlp), L.ptr(w.bmlp), L.ptr(t1), L.ptr(y), st)
+    if save:
+        return y, SwinSaved(d, tb, x, q, k, v, kp, vp, qa, ka, o, lse, t1)
+    return y, None
