@@ -187,13 +187,14 @@ typedef struct MivpConvDesc {
 int mivp_conv3d_fwd(const MivpConvDesc* d, const void* x, const void* w, const float* bias,
                     const float* scale, const float* shift, const void* residual, void* y,
                     mivp_stream_t stream);
-/* weight gradient for small Cout (segmentation heads):
- *   dw [Cout][27][Cin] f32 += sum_v dy[v][co] * x'[v+tap][ci] ; db [Cout] f32
- *   dy [B,vol,Cp] bf16 with Cp channels per voxel (>= Cout) ; partial sums land in part[] and are
- *   reduced deterministically; part needs mivp_conv3d_wgrad_small_ws(d) floats                  */
+/* weight + bias gradient for small Cout (segmentation heads, Cout <= 8):
+ *   dwdb [Cout*27*Cin + Cout] f32 : dw[co][tap][ci] = sum_v dy[v][co] * x'[v+tap][ci] followed by db[co]
+ *   (x' = the operand the forward conv saw, i.e. after the fused scale/shift/activation);
+ *   dy [B,vol,dy_stride] bf16 with dy_stride >= Cout channels per voxel ; per-workgroup partial sums
+ *   land in part[] (mivp_conv3d_wgrad_small_ws(d) floats) and are reduced deterministically.        */
 size_t mivp_conv3d_wgrad_small_ws(const MivpConvDesc* d);
 int mivp_conv3d_wgrad_small(const MivpConvDesc* d, const void* x, const float* scale, const float* shift,
-                            const void* dy, int32_t dy_stride, float* part, float* dw, float* db,
+                            const void* dy, int32_t dy_stride, float* part, float* dwdb,
                             mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */

@@ -1,0 +1,311 @@
+// Patch merging (encoder downsample) and trilinear upsample + crop + concat (decoder).
+// Reference: swin_transformer/down.py:21-53 ; swin_unetr/unet_blocks.py:31-35,72-73 and
+// swin_unetr/swin_unetr.py:351-355 (nn.Upsample(trilinear, align_corners=False)).
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// K4  patch merging forward: gather 8 (or 4) neighbours -> LayerNorm(kC) -> Linear(kC -> Cout)
+//   odd axes are zero-padded by one AT THE FRONT (down.py:25-28), also D when it is not merged;
+//   concat order (h,w,d): 000 100 010 001 110 101 011 111   /  (h,w): 00 10 01 11
+//   one wave = 16 output tokens; the gathered row goes straight into the MFMA B lane map.
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ int c_off8[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+__device__ __constant__ int c_off4[4][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0}};
+
+struct MergeTok { long b; int o[3]; bool live; };
+
+MIVP_DEV MergeTok merge_token(const MivpMergeDesc& d, long t) {
+    MergeTok m;
+    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
+    const long T = (long)d.B * ovol;
+    m.live = t < T;
+    const long tt = m.live ? t : 0;
+    m.b = tt / ovol;
+    long rem = tt - m.b * ovol;
+    m.o[0] = (int)(rem / ((long)d.odims[1] * d.odims[2]));
+    rem -= (long)m.o[0] * d.odims[1] * d.odims[2];
+    m.o[1] = (int)(rem / d.odims[2]);
+    m.o[2] = (int)(rem - (long)m.o[1] * d.odims[2]);
+    return m;
+}
+
+// input voxel offset of concat part `part` for output token m, or -1 when it falls in the front pad
+MIVP_DEV long merge_src(const MivpMergeDesc& d, const MergeTok& m, int part) {
+    int xc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int pad = d.dims[a] & 1;
+        const bool merged = a < 2 || d.merge_last;
+        const int off = d.merge_last ? c_off8[part][a] : c_off4[part][a];
+        const int f = merged ? 2 * m.o[a] + off : m.o[a];
+        xc[a] = f - pad;
+    }
+    if (xc[0] < 0 || xc[1] < 0 || xc[2] < 0) return -1;
+    return ((m.b * d.dims[0] + xc[0]) * (long)d.dims[1] + xc[1]) * d.dims[2] + xc[2];
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         const bf16_t* __restrict__ w, bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C;
+    const int kC = (d.merge_last ? 8 : 4) * C;
+    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
+    const MergeTok m = merge_token(d, t);
+
+    float xs[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[s][i] = 0.f;
+        if (m.live && c < kC) {
+            const int part = c / C, ch = c - part * C;
+            const long src = merge_src(d, m, part);
+            if (src >= 0) {
+                const bf16x8 raw = ld8(x + src * C + ch);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { xs[s][i] = (float)raw[i]; sum += xs[s][i]; }
+            }
+        }
+    }
+    const float mean = col_sum(sum) / (float)kC;
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (32 * s + 8 * g < kC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dv = xs[s][i] - mean; var += dv * dv; }
+        }
+    }
+    const float rstd = rsqrtf(col_sum(var) / (float)kC + d.ln_eps);
+    bf16x8 xb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+        bf16x8 yv = zero8();
+        if (m.live && c < kC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yv[i] = (bf16_t)((xs[s][i] - mean) * rstd * ln_w[c + i] + ln_b[c + i]);
+        }
+        xb[s] = yv;
+    }
+    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
+    const int n_tiles = (d.Cout + 15) / 16;
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        f32x4 acc = fzero4();
+        const int nrow = 16 * nt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (nrow < d.Cout && c < kC) a = ld8(w + (long)nrow * kC + c);
+            acc = mfma16(a, xb[s], acc);
+        }
+        const int n0 = 16 * nt + 4 * g;
+        if (m.live && n0 < d.Cout) st4(y + t * d.Cout + n0, pack4(acc));
+    }
+    (void)ovol;
+}
+
+extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const float* ln_w, const float* ln_b,
+                                    const void* w, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && ln_w && ln_b && w && y);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->Cout % 4 == 0);
+    for (int a = 0; a < 3; ++a) {
+        const int padded = d->dims[a] + (d->dims[a] & 1);
+        const bool merged = a < 2 || d->merge_last;
+        MIVP_REQUIRE(d->odims[a] == (merged ? padded / 2 : padded));
+    }
+    const int kC = (d->merge_last ? 8 : 4) * d->C;
+    const int KS = (kC + 31) / 32;
+    const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PM(K) hipLaunchKernelGGL((k_patch_merge_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)x, ln_w, ln_b, \
+                                         (const bf16_t*)w, (bf16_t*)y)
+    switch (KS) {
+        case 1: LAUNCH_PM(1); break;
+        case 2: LAUNCH_PM(2); break;
+        case 4: LAUNCH_PM(4); break;
+        case 6: LAUNCH_PM(6); break;
+        case 8: LAUNCH_PM(8); break;
+        case 12: LAUNCH_PM(12); break;
+        case 24: LAUNCH_PM(24); break;
+        default: mivp_set_error("patch_merge_fwd: k*C/32 not in {1,2,4,6,8,12,24}"); return MIVP_EUNSUPPORTED;
+    }
+#undef LAUNCH_PM
+    return mivp_check_launch("patch_merge_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// trilinear upsample (align_corners=False, scale 1 or 2 per axis) + crop to the skip's dims + concat
+//   source index as ATen's area_pixel_compute_source_index: max(0, (o + 0.5) / scale - 0.5)
+// ---------------------------------------------------------------------------------------------
+struct Lerp { int i0, i1; float w0, w1; };
+
+MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in) {
+    Lerp l;
+    if (scale == 1) { l.i0 = l.i1 = o; l.w0 = 1.f; l.w1 = 0.f; return l; }
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    if (src < 0.f) src = 0.f;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < n_in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t* __restrict__ x,
+                                                   const bf16_t* __restrict__ skip, bf16_t* __restrict__ y) {
+    const int Ct = d.Cx + d.Cs, G = Ct / 8, Gx = d.Cx / 8;
+    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
+    const long items = (long)d.B * ovol * G;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long it = gtid; it < items; it += stride) {
+        const long vox = it / G;
+        const int cg = (int)(it - vox * G);
+        if (cg >= Gx) {
+            st8(y + vox * Ct + cg * 8, ld8(skip + vox * d.Cs + (cg - Gx) * 8));
+            continue;
+        }
+        const long b = vox / ovol;
+        long rem = vox - b * ovol;
+        const int oh = (int)(rem / ((long)d.odims[1] * d.odims[2]));
+        rem -= (long)oh * d.odims[1] * d.odims[2];
+        const int ow = (int)(rem / d.odims[2]);
+        const int od = (int)(rem - (long)ow * d.odims[2]);
+        const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0]);
+        const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1]);
+        const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2]);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const int hs[2] = {lh.i0, lh.i1}, wsx[2] = {lw.i0, lw.i1}, ds[2] = {ld.i0, ld.i1};
+        const float hw[2] = {lh.w0, lh.w1}, ww[2] = {lw.w0, lw.w1}, dw[2] = {ld.w0, ld.w1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float wgt = hw[a] * ww[bb] * dw[c];
+                    if (wgt != 0.f) {
+                        const bf16x8 v = ld8(x + (((b * d.idims[0] + hs[a]) * (long)d.idims[1] + wsx[bb]) * d.idims[2] + ds[c]) * d.Cx + cg * 8);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] += wgt * (float)v[i];
+                    }
+                }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)acc[i];
+        st8(y + vox * Ct + cg * 8, o);
+    }
+}
+
+extern "C" int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && y);
+    MIVP_REQUIRE(d->Cx % 8 == 0 && d->Cs % 8 == 0 && (d->Cs == 0 || skip));
+    for (int a = 0; a < 3; ++a) {
+        MIVP_REQUIRE(d->scale[a] == 1 || d->scale[a] == 2);
+        MIVP_REQUIRE(d->odims[a] > 0 && d->odims[a] <= d->scale[a] * d->idims[a]);
+    }
+    const long items = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2] * ((d->Cx + d->Cs) / 8);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(k_upcat_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)x,
+                       (const bf16_t*)skip, (bf16_t*)y);
+    return mivp_check_launch("upcat_fwd");
+}
+
+// backward: dx[i] = sum over output positions o whose stencil touches i of weight(o, i) * dy[o] (first Cx
+// channels of dy); dskip = channel slice copy.  Gather form: per axis at most 4 candidate outputs.
+__global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16_t* __restrict__ dy,
+                                                     bf16_t* __restrict__ dx) {
+    const int Ct = d.Cx + d.Cs, Gx = d.Cx / 8;
+    const long ivol = (long)d.idims[0] * d.idims[1] * d.idims[2];
+    const long items = (long)d.B * ivol * Gx;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long it = gtid; it < items; it += stride) {
+        const long vox = it / Gx;
+        const int cg = (int)(it - vox * Gx);
+        const long b = vox / ivol;
+        long rem = vox - b * ivol;
+        const int ih = (int)(rem / ((long)d.idims[1] * d.idims[2]));
+        rem -= (long)ih * d.idims[1] * d.idims[2];
+        const int iw = (int)(rem / d.idims[2]);
+        const int id = (int)(rem - (long)iw * d.idims[2]);
+        const int ic[3] = {ih, iw, id};
+        int cand[3][4];
+        float cw[3][4];
+        int ncand[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ncand[a] = 0;
+            const int lo = d.scale[a] == 1 ? ic[a] : 2 * ic[a] - 1;
+            const int hi = d.scale[a] == 1 ? ic[a] : 2 * ic[a] + 2;
+            for (int o = lo; o <= hi; ++o) {
+                if (o < 0 || o >= d.odims[a]) continue;
+                const Lerp l = lerp_axis(o, d.scale[a], d.idims[a]);
+                float wgt = 0.f;
+                if (l.i0 == ic[a]) wgt += l.w0;
+                if (l.i1 == ic[a]) wgt += l.w1;
+                if (wgt != 0.f) { cand[a][ncand[a]] = o; cw[a][ncand[a]] = wgt; ++ncand[a]; }
+            }
+        }
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int a = 0; a < ncand[0]; ++a)
+            for (int bb = 0; bb < ncand[1]; ++bb)
+                for (int c = 0; c < ncand[2]; ++c) {
+                    const float wgt = cw[0][a] * cw[1][bb] * cw[2][c];
+                    const long ov = ((b * d.odims[0] + cand[0][a]) * (long)d.odims[1] + cand[1][bb]) * d.odims[2] + cand[2][c];
+                    const bf16x8 v = ld8(dy + ov * Ct + cg * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += wgt * (float)v[i];
+                }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)acc[i];
+        st8(dx + vox * d.Cx + cg * 8, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_upcat_bwd_skip(MivpUpcatDesc d, const bf16_t* __restrict__ dy,
+                                                        bf16_t* __restrict__ dskip) {
+    const int Ct = d.Cx + d.Cs, Gs = d.Cs / 8;
+    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
+    const long items = (long)d.B * ovol * Gs;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long it = gtid; it < items; it += stride) {
+        const long vox = it / Gs;
+        const int cg = (int)(it - vox * Gs);
+        st8(dskip + vox * d.Cs + cg * 8, ld8(dy + vox * Ct + d.Cx + cg * 8));
+    }
+}
+
+extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && dy);
+    MIVP_REQUIRE(d->Cx % 8 == 0 && d->Cs % 8 == 0);
+    if (dx) {
+        const long items = (long)d->B * d->idims[0] * d->idims[1] * d->idims[2] * (d->Cx / 8);
+        const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+        hipLaunchKernelGGL(k_upcat_bwd_x, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy, (bf16_t*)dx);
+        int rc = mivp_check_launch("upcat_bwd_x");
+        if (rc) return rc;
+    }
+    if (dskip && d->Cs > 0) {
+        const long items = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2] * (d->Cs / 8);
+        const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+        hipLaunchKernelGGL(k_upcat_bwd_skip, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy,
+                           (bf16_t*)dskip);
+        return mivp_check_launch("upcat_bwd_skip");
+    }
+    return MIVP_OK;
+}

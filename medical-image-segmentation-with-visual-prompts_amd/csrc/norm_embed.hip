@@ -1,0 +1,280 @@
+// Patch embedding (Conv3d k=s=2) and training-mode BatchNorm3d pieces on channels-last bf16.
+// Reference: swin_unetr/swin_unetr.py:148-158 (input_layer), :229-237 (head BatchNorm),
+// swin_unetr/unet_blocks.py:41-45,74 (norm_concat).  All of these are HBM-bound: 16-byte
+// accesses, per-thread fp32 partials, LDS atomics per workgroup, deterministic final reduction.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// patch embedding: y[b,h,w,d,co] = bias[co] + sum_{ci,a,b,c} x[b,ci,2h+a,2w+b,2d+c] * w[co,ci,a,b,c]
+//   work item = (output voxel, group of 8 output channels); total threads is a multiple of C/8 so a
+//   thread keeps one channel group for its whole grid-stride walk.
+//   mode 0: per-channel sum / sum of squares -> part[block][2C]     mode 1: affine + bf16 store
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ part, bf16_t* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = d.C, Cin = d.Cin, G = C / 8;
+    float* wl = reinterpret_cast<float*>(smem);               // [C][Cin*8]
+    float* lsum = wl + C * Cin * 8;                            // [2C]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * Cin * 8; i += 256) wl[i] = w[i];
+    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    const int H = d.dims[0], W = d.dims[1], D = d.dims[2];
+    const int oh = H / 2, ow = W / 2, od = D / 2;
+    const long ovol = (long)oh * ow * od, ivol = (long)H * W * D;
+    const long items = (long)d.B * ovol * G;
+    const long gtid = (long)blockIdx.x * 256 + tid;
+    const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (long it = gtid; it < items; it += stride) {
+        const long vox = it / G;
+        const long b = vox / ovol;
+        long rem = vox - b * ovol;
+        const int h = (int)(rem / ((long)ow * od));
+        rem -= (long)h * ow * od;
+        const int ww = (int)(rem / od);
+        const int z = (int)(rem - (long)ww * od);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xb = x + (b * Cin + ci) * ivol;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const float2 xv = *reinterpret_cast<const float2*>(xb + ((long)(2 * h + a) * W + (2 * ww + bb)) * D + 2 * z);
+                    const int wo = ci * 8 + a * 4 + bb * 2;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float* wr = wl + (cg * 8 + i) * Cin * 8 + wo;
+                        acc[i] += xv.x * wr[0] + xv.y * wr[1];
+                    }
+                }
+        }
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += acc[i]; s2[i] += acc[i] * acc[i]; }
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (bf16_t)(acc[i] * scale[cg * 8 + i] + shift[cg * 8 + i]);
+            st8(y + vox * C + cg * 8, o);
+        }
+    }
+    if (mode == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
+    }
+}
+
+extern "C" int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x, const float* w, const float* bias,
+                                const float* scale, const float* shift, float* part, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && w && bias);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->Cin > 0 && d->nblk > 0);
+    MIVP_REQUIRE(d->dims[0] % 2 == 0 && d->dims[1] % 2 == 0 && d->dims[2] % 2 == 0);
+    MIVP_REQUIRE((d->nblk * 256) % (d->C / 8) == 0);
+    MIVP_REQUIRE(mode == 0 ? part != nullptr : (y && scale && shift));
+    const size_t lds = ((size_t)d->C * d->Cin * 8 + 2 * d->C) * sizeof(float);
+    hipLaunchKernelGGL(k_patch_embed, dim3(d->nblk), dim3(256), lds, (hipStream_t)stream, *d, mode, x, w, bias, scale,
+                       shift, part, (bf16_t*)y);
+    return mivp_check_launch("patch_embed");
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics of a bf16 [n_vox][C] tensor
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_stats(const bf16_t* __restrict__ x, long n_vox, int C,
+                                                  float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lsum = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, G = C / 8;
+    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    const long items = n_vox * G;
+    const long gtid = (long)blockIdx.x * 256 + tid;
+    const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (long it = gtid; it < items; it += stride) {
+        const bf16x8 v = ld8(x + it * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
+}
+
+extern "C" int mivp_bn_stats(const void* x, int64_t n_vox, int32_t C, int32_t nblk, float* part, mivp_stream_t stream) {
+    MIVP_REQUIRE(x && part && n_vox > 0 && C % 8 == 0 && nblk > 0);
+    MIVP_REQUIRE((nblk * 256) % (C / 8) == 0);
+    hipLaunchKernelGGL(k_bn_stats, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
+                       (long)n_vox, (int)C, part);
+    return mivp_check_launch("bn_stats");
+}
+
+// part [nblk][2C] -> batch mean / biased var -> scale, shift ; running stats (unbiased var) ; mean_rstd
+__global__ void k_bn_finalize(const float* __restrict__ part, int nblk, int C, double count, const float* __restrict__ w,
+                              const float* __restrict__ b, float eps, float momentum, float* __restrict__ rmean,
+                              float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                              float* __restrict__ mean_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nblk; ++i) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (w ? w[c] : 1.f) * rstd;
+    scale[c] = sc;
+    shift[c] = (b ? b[c] : 0.f) - (float)mean * sc;
+    if (mean_rstd) { mean_rstd[c] = (float)mean; mean_rstd[C + c] = rstd; }
+    if (rmean && rvar) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+extern "C" int mivp_bn_finalize(const float* part, int32_t nblk, int32_t C, double count, const float* w, const float* b,
+                                float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                float* shift, float* mean_rstd, mivp_stream_t stream) {
+    MIVP_REQUIRE(part && scale && shift && nblk > 0 && C > 0 && count > 0);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, (int)nblk, (int)C, count,
+                       w, b, eps, momentum, running_mean, running_var, scale, shift, mean_rstd);
+    return mivp_check_launch("bn_finalize");
+}
+
+__global__ __launch_bounds__(256) void k_affine_act(const bf16_t* __restrict__ x, long n_vox, int C,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    int lrelu, bf16_t* __restrict__ y) {
+    const int G = C / 8;
+    const long items = n_vox * G;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long it = gtid; it < items; it += stride) {
+        const int cg = (int)(it % G);
+        const bf16x8 v = ld8(x + it * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float f = (float)v[i] * scale[cg * 8 + i] + shift[cg * 8 + i];
+            if (lrelu) f = f > 0.f ? f : 0.01f * f;
+            o[i] = (bf16_t)f;
+        }
+        st8(y + it * 8, o);
+    }
+}
+
+extern "C" int mivp_affine_act(const void* x, int64_t n_vox, int32_t C, const float* scale, const float* shift,
+                               int32_t lrelu, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(x && y && scale && shift && n_vox > 0 && C % 8 == 0);
+    const long items = n_vox * (C / 8);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    hipLaunchKernelGGL(k_affine_act, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)n_vox, (int)C,
+                       scale, shift, (int)lrelu, (bf16_t*)y);
+    return mivp_check_launch("affine_act");
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward (training mode): z = x*scale + shift, y = act(z)
+//   dz = dy * act'(z) ; sums: S1 = sum dz, S2 = sum dz * xhat ; xhat = (x - mean) * rstd
+//   dx = scale * (dz - S1/n - xhat * S2/n)        (scale = gamma * rstd)
+//   dgamma = S2, dbeta = S1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                      long n_vox, int C, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ mean_rstd,
+                                                      int lrelu, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lsum = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, G = C / 8;
+    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    const long items = n_vox * G;
+    const long gtid = (long)blockIdx.x * 256 + tid;
+    const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
+    float s1[8], s2[8], sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s1[i] = 0.f; s2[i] = 0.f;
+        sc[i] = scale[cg * 8 + i]; sh[i] = shift[cg * 8 + i];
+        mu[i] = mean_rstd[cg * 8 + i]; rs[i] = mean_rstd[C + cg * 8 + i];
+    }
+    for (long it = gtid; it < items; it += stride) {
+        const bf16x8 xv = ld8(x + it * 8), gv = ld8(dy + it * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xf = (float)xv[i];
+            float gz = (float)gv[i];
+            if (lrelu && xf * sc[i] + sh[i] <= 0.f) gz *= 0.01f;
+            s1[i] += gz;
+            s2[i] += gz * (xf - mu[i]) * rs[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
+}
+
+extern "C" int mivp_bn_bwd_stats(const void* x, const void* dy, int64_t n_vox, int32_t C, const float* scale,
+                                 const float* shift, const float* mean_rstd, int32_t lrelu, int32_t nblk, float* part,
+                                 mivp_stream_t stream) {
+    MIVP_REQUIRE(x && dy && scale && shift && mean_rstd && part && n_vox > 0 && C % 8 == 0 && nblk > 0);
+    MIVP_REQUIRE((nblk * 256) % (C / 8) == 0);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)dy, (long)n_vox, (int)C, scale, shift, mean_rstd, (int)lrelu, part);
+    return mivp_check_launch("bn_bwd_stats");
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                      long n_vox, int C, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ mean_rstd,
+                                                      const float* __restrict__ sums, int lrelu, bf16_t* __restrict__ dx) {
+    const int G = C / 8;
+    const long items = n_vox * G;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const float inv_n = 1.0f / (float)n_vox;
+    for (long it = gtid; it < items; it += stride) {
+        const int cg = (int)(it % G);
+        const bf16x8 xv = ld8(x + it * 8), gv = ld8(dy + it * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cg * 8 + i;
+            const float xf = (float)xv[i];
+            float gz = (float)gv[i];
+            if (lrelu && xf * scale[c] + shift[c] <= 0.f) gz *= 0.01f;
+            const float xhat = (xf - mean_rstd[c]) * mean_rstd[C + c];
+            o[i] = (bf16_t)(scale[c] * (gz - sums[c] * inv_n - xhat * sums[C + c] * inv_n));
+        }
+        st8(dx + it * 8, o);
+    }
+}
+
+extern "C" int mivp_bn_bwd_apply(const void* x, const void* dy, int64_t n_vox, int32_t C, const float* scale,
+                                 const float* shift, const float* mean_rstd, const float* sums, int32_t lrelu, void* dx,
+                                 mivp_stream_t stream) {
+    MIVP_REQUIRE(x && dy && scale && shift && mean_rstd && sums && dx && n_vox > 0 && C % 8 == 0);
+    const long items = n_vox * (C / 8);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy,
+                       (long)n_vox, (int)C, scale, shift, mean_rstd, sums, (int)lrelu, (bf16_t*)dx);
+    return mivp_check_launch("bn_bwd_apply");
+}

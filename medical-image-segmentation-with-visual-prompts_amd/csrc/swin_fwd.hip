@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 
 // ---------------------------------------------------------------------------------------------
 // K1b  window attention forward, one workgroup per (window instance, head)
-//   LDS: K' image [Nkp][DK+8], Q' image [Nqp][DK+8] (rows = head dims | bias aug | zero pad),
-//        V^T image [16*DVT][Nkp+8], key region ids.
+//   LDS: K' image [Nkp][DK+8] (rows = head dims | bias aug | zero pad), V^T image [16*DVT][Nkp+8],
+//        key region ids.  Q' fragments are assembled per query tile straight from global.
 //   Each wave walks 16-query tiles; S^T = K' Q'^T puts ONE query on each lane, so the softmax
 //   row reductions are in-lane + 2 shuffles and P feeds the PV MFMA with no lane movement
 //   (k index permuted identically on both operands).
@@ -215,8 +215,7 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
     const int Nkp = d.Nkp, Nqp = d.Nqp;
     const int VROW = (Nkp + 8) * 2;                          // bytes
     char* Kimg = smem;
-    char* Qimg = Kimg + (size_t)Nkp * KROW;
-    char* Vt = Qimg + (size_t)Nqp * KROW;
+    char* Vt = Kimg + (size_t)Nkp * KROW;
     int* ridk = reinterpret_cast<int*>(Vt + (size_t)(16 * DVT) * VROW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,14 +239,6 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
             val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
         }
         *reinterpret_cast<bf16x4*>(Kimg + (size_t)row * KROW + 8 * c4) = val;
-    }
-    // ---- stage Q' ----
-    for (int e = tid; e < Nqp * dk4; e += 256) {
-        const int row = e / dk4, c4 = e - row * dk4;
-        bf16x4 val = zero4();
-        if (c4 < hd4) val = ld4(q + ((bph * Nqp + row) * (long)hd + 4 * c4));
-        else if (c4 < hd4 + a4) val = ld4(qa + ((long)row * A + 4 * (c4 - hd4)));
-        *reinterpret_cast<bf16x4*>(Qimg + (size_t)row * KROW + 8 * c4) = val;
     }
     // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows) ----
     for (int e = tid; e < Nkp * (4 * DVT); e += 256) {
@@ -277,9 +268,21 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
     for (int qt = wave; qt < Nqp / 16; qt += 4) {
         const int qrow = qt * 16 + r;
         const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
         bf16x8 qf[DKS];
 #pragma unroll
-        for (int s = 0; s < DKS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qimg + (size_t)qrow * KROW + (32 * s + 8 * g) * 2);
+        for (int s = 0; s < DKS; ++s) {
+            bf16x4 piece[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int c4 = 8 * s + 2 * g + hlf;
+                bf16x4 val = zero4();
+                if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
+                else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
+                piece[hlf] = val;
+            }
+            qf[s] = cat44(piece[0], piece[1]);
+        }
 
         f32x4 S[NT];
         float mx = -INFINITY;
@@ -534,7 +537,7 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
                            const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
                            hipStream_t st) {
     const size_t krow = (32 * DKS + 8) * 2, vrow = (d->Nkp + 8) * 2;
-    const size_t lds = (size_t)d->Nkp * krow + (size_t)d->Nqp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
+    const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     auto kern = k_win_attn_fwd<NT, DKS, DVT>;
     if (lds > 64 * 1024) {

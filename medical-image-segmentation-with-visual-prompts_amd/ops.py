@@ -1,0 +1,246 @@
+"""Host wrappers of the non-attention kernels (conv, norm, merge, upsample) around the C ABI.
+
+Everything here is plumbing: shape bookkeeping, buffer allocation through torch,
+weight re-layout (done once per weight version), one HIP launch per op.
+"""
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .geometry import round_up
+
+BF16 = torch.bfloat16
+
+
+def _nblk(items: int, groups: int, cap: int = 1024) -> int:
+    """Number of 256-thread blocks for a grid-stride kernel whose threads keep a fixed
+    channel group: (nblk*256) % groups == 0."""
+    want = max(1, min(cap, (items + 255) // 256))
+    import math
+    step = groups // math.gcd(groups, 256)
+    return max(step, (want // step) * step)
+
+
+# ------------------------------------------------------------------------------------------
+# conv 3x3x3
+# ------------------------------------------------------------------------------------------
+def pack_conv_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """nn.Conv3d weight [Cout, Cin, 3,3,3] -> bf16 [Cout_p, Kp], k = tap*Cin_p + ci, tap = (kh*3+kw)*3+kd."""
+    cout, cin = w.shape[0], w.shape[1]
+    cin_p = cin_pad or round_up(cin, 8)
+    wt = w.detach().float().permute(0, 2, 3, 4, 1).reshape(cout, 27, cin)
+    if cin_p != cin:
+        wt = torch.nn.functional.pad(wt, (0, cin_p - cin))
+    k = 27 * cin_p
+    kp = round_up(k, 32)
+    out = torch.zeros((round_up(cout, 16), kp), dtype=torch.float32, device=w.device)
+    out[:cout, :k] = wt.reshape(cout, k)
+    return out.to(BF16).contiguous()
+
+
+def pack_conv_weight_dgrad(w: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Weights of the data-gradient convolution: dgrad of a stride-1 pad-1 3^3 conv is the same conv of
+    dy with taps flipped and Cin/Cout swapped.  dy is expected with channels padded to a multiple of 8."""
+    wf = w.detach().float().flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()     # [Cin, Cout, 3,3,3]
+    cpad = round_up(w.shape[0], 8)
+    return pack_conv_weight(wf, cin_pad=cpad), cpad
+
+
+def conv_desc(B, dims, cin, cout, affine, lrelu, residual, out_f32) -> L.ConvDesc:
+    d = L.ConvDesc()
+    d.B = B
+    for a in range(3):
+        d.dims[a] = int(dims[a])
+    d.Cin, d.Cout = cin, cout
+    d.Kp = round_up(27 * cin, 32)
+    d.pro_affine = 1 if affine else 0
+    d.pro_lrelu = 1 if lrelu else 0
+    d.add_residual = 1 if residual else 0
+    d.out_f32 = 1 if out_f32 else 0
+    return d
+
+
+def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+           scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, lrelu: bool = False,
+           residual: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    B, H, W, D, cin = x.shape
+    d = conv_desc(B, (H, W, D), cin, cout, scale is not None, lrelu, residual is not None, out_f32)
+    if wp.shape != (round_up(cout, 16), d.Kp):
+        raise RuntimeError(f"conv3d: packed weight shape {tuple(wp.shape)} does not match Cout={cout}, Cin={cin}")
+    y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    L.call("mivp_conv3d_fwd", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+           L.ptr(residual), L.ptr(y), L.stream())
+    return y
+
+
+def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
+    """dw [Cout,Cin,3,3,3] f32 and db [Cout] f32 for a small-Cout conv (segmentation heads)."""
+    B, H, W, D, cin = x.shape
+    d = conv_desc(B, (H, W, D), cin, cout, scale is not None, lrelu, False, False)
+    ws = L.lib().mivp_conv3d_wgrad_small_ws(C.byref(d))
+    part = torch.empty(ws, dtype=torch.float32, device=x.device)
+    out = torch.empty(cout * 27 * cin + cout, dtype=torch.float32, device=x.device)
+    L.call("mivp_conv3d_wgrad_small", C.byref(d), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dy),
+           C.c_int32(dy.shape[-1]), L.ptr(part), L.ptr(out), L.stream())
+    dw = out[:cout * 27 * cin].reshape(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3).contiguous()
+    return dw, out[cout * 27 * cin:].clone()
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm (training mode)
+# ------------------------------------------------------------------------------------------
+def bn_finalize(part, nblk, Cc, count, weight, bias, eps, running_mean, running_var, momentum=0.1):
+    dev = part.device
+    scale = torch.empty(Cc, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean_rstd = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+    L.call("mivp_bn_finalize", L.ptr(part), C.c_int32(nblk), C.c_int32(Cc), C.c_double(float(count)), L.ptr(weight),
+           L.ptr(bias), C.c_float(eps), C.c_float(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(scale),
+           L.ptr(shift), L.ptr(mean_rstd), L.stream())
+    return scale, shift, mean_rstd
+
+
+def bn_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.1):
+    """Batch statistics of a bf16 channels-last tensor -> (scale, shift, mean_rstd); running stats updated in place."""
+    Cc = x.shape[-1]
+    n_vox = x.numel() // Cc
+    nblk = _nblk(n_vox * (Cc // 8), Cc // 8)
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+    L.call("mivp_bn_stats", L.ptr(x), C.c_int64(n_vox), C.c_int32(Cc), C.c_int32(nblk), L.ptr(part), L.stream())
+    return bn_finalize(part, nblk, Cc, n_vox, weight, bias, eps, running_mean, running_var, momentum)
+
+
+def bn_eval_affine(weight, bias, running_mean, running_var, eps):
+    """Eval-mode BatchNorm as a per-channel affine (parameter-only arithmetic)."""
+    rstd = torch.rsqrt(running_var.float() + eps)
+    scale = (weight.float() * rstd).contiguous()
+    shift = (bias.float() - running_mean.float() * scale).contiguous()
+    return scale, shift, torch.cat([running_mean.float(), rstd]).contiguous()
+
+
+def affine_act(x, scale, shift, lrelu=False):
+    y = torch.empty_like(x)
+    Cc = x.shape[-1]
+    L.call("mivp_affine_act", L.ptr(x), C.c_int64(x.numel() // Cc), C.c_int32(Cc), L.ptr(scale), L.ptr(shift),
+           C.c_int32(1 if lrelu else 0), L.ptr(y), L.stream())
+    return y
+
+
+def bn_backward(x, dy, scale, shift, mean_rstd, lrelu):
+    """Training-mode BN (+ optional LeakyReLU) backward: returns dx (bf16), dgamma, dbeta (f32)."""
+    Cc = x.shape[-1]
+    n_vox = x.numel() // Cc
+    nblk = _nblk(n_vox * (Cc // 8), Cc // 8)
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+    L.call("mivp_bn_bwd_stats", L.ptr(x), L.ptr(dy), C.c_int64(n_vox), C.c_int32(Cc), L.ptr(scale), L.ptr(shift),
+           L.ptr(mean_rstd), C.c_int32(1 if lrelu else 0), C.c_int32(nblk), L.ptr(part), L.stream())
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+    L.call("mivp_reduce_rows", L.ptr(part), C.c_int64(nblk), C.c_int64(2 * Cc), L.ptr(sums), L.stream())
+    dx = torch.empty_like(x)
+    L.call("mivp_bn_bwd_apply", L.ptr(x), L.ptr(dy), C.c_int64(n_vox), C.c_int32(Cc), L.ptr(scale), L.ptr(shift),
+           L.ptr(mean_rstd), L.ptr(sums), C.c_int32(1 if lrelu else 0), L.ptr(dx), L.stream())
+    return dx, sums[Cc:], sums[:Cc]
+
+
+# ------------------------------------------------------------------------------------------
+# patch embedding (+ its BatchNorm)
+# ------------------------------------------------------------------------------------------
+def patch_embed(x, w, bias, bn_w, bn_b, eps, running_mean, running_var, training=True, momentum=0.1):
+    """x f32 [B, Cin, H, W, D] -> bf16 [B, H/2, W/2, D/2, C] = BN(conv_k2s2(x))."""
+    B, cin, H, W, D = x.shape
+    Cc = w.shape[0]
+    d = L.EmbedDesc()
+    d.B, d.Cin, d.C = B, cin, Cc
+    for a, v in enumerate((H, W, D)):
+        d.dims[a] = v
+    n_out = B * (H // 2) * (W // 2) * (D // 2)
+    d.nblk = _nblk(n_out * (Cc // 8), Cc // 8, cap=2048)
+    x = x.contiguous().float()
+    w = w.detach().float().contiguous()
+    bias = bias.detach().float().contiguous()
+    st = L.stream()
+    if training:
+        part = torch.empty((d.nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+        L.call("mivp_patch_embed", C.byref(d), C.c_int(0), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(None), L.ptr(None),
+               L.ptr(part), L.ptr(None), st)
+        scale, shift, mean_rstd = bn_finalize(part, d.nblk, Cc, n_out, bn_w, bn_b, eps, running_mean, running_var, momentum)
+    else:
+        scale, shift, mean_rstd = bn_eval_affine(bn_w, bn_b, running_mean, running_var, eps)
+    y = torch.empty((B, H // 2, W // 2, D // 2, Cc), dtype=BF16, device=x.device)
+    L.call("mivp_patch_embed", C.byref(d), C.c_int(1), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+           L.ptr(None), L.ptr(y), st)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# patch merging
+# ------------------------------------------------------------------------------------------
+def merge_desc(B, dims, Cc, cout, merge_last) -> L.MergeDesc:
+    d = L.MergeDesc()
+    d.B, d.C, d.Cout = B, Cc, cout
+    d.merge_last = 1 if merge_last else 0
+    d.ln_eps = 1e-6
+    for a in range(3):
+        d.dims[a] = int(dims[a])
+        padded = dims[a] + (dims[a] & 1)
+        d.odims[a] = padded // 2 if (a < 2 or merge_last) else padded
+    return d
+
+
+def patch_merge(x, ln_w, ln_b, w_bf16, merge_last):
+    B, H, W, D, Cc = x.shape
+    cout = w_bf16.shape[0]
+    d = merge_desc(B, (H, W, D), Cc, cout, merge_last)
+    y = torch.empty((B, d.odims[0], d.odims[1], d.odims[2], cout), dtype=BF16, device=x.device)
+    L.call("mivp_patch_merge_fwd", C.byref(d), L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w_bf16), L.ptr(y), L.stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# trilinear upsample + crop + concat
+# ------------------------------------------------------------------------------------------
+def upcat_desc(B, idims, odims, scale, cx, cs) -> L.UpcatDesc:
+    d = L.UpcatDesc()
+    d.B, d.Cx, d.Cs = B, cx, cs
+    for a in range(3):
+        d.idims[a], d.odims[a], d.scale[a] = int(idims[a]), int(odims[a]), int(scale[a])
+    return d
+
+
+def upcat(x, skip, scale: Sequence[int], odims: Optional[Sequence[int]] = None):
+    B, ih, iw, id_, cx = x.shape
+    if skip is not None:
+        odims = skip.shape[1:4]
+        cs = skip.shape[-1]
+    else:
+        cs = 0
+        odims = odims or (ih * scale[0], iw * scale[1], id_ * scale[2])
+    d = upcat_desc(B, (ih, iw, id_), odims, scale, cx, cs)
+    y = torch.empty((B, odims[0], odims[1], odims[2], cx + cs), dtype=BF16, device=x.device)
+    L.call("mivp_upcat_fwd", C.byref(d), L.ptr(x), L.ptr(skip), L.ptr(y), L.stream())
+    return y
+
+
+def upcat_backward(dy, idims, scale, cx, cs, need_skip=True):
+    B = dy.shape[0]
+    odims = dy.shape[1:4]
+    d = upcat_desc(B, idims, odims, scale, cx, cs)
+    dx = torch.empty((B, idims[0], idims[1], idims[2], cx), dtype=BF16, device=dy.device)
+    dskip = torch.empty((B, odims[0], odims[1], odims[2], cs), dtype=BF16, device=dy.device) if (cs and need_skip) else None
+    L.call("mivp_upcat_bwd", C.byref(d), L.ptr(dy), L.ptr(dx), L.ptr(dskip), L.stream())
+    return dx, dskip
+
+
+def cast_bf16(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach().float().contiguous()
+    out = torch.empty(t.shape, dtype=BF16, device=t.device)
+    L.call("mivp_cast_f32_bf16", L.ptr(t), C.c_int64(t.numel()), L.ptr(out), L.stream())
+    return out
+
+
+def add_bf16(a, b):
+    y = torch.empty_like(a)
+    L.call("mivp_add_bf16", L.ptr(a), L.ptr(b), C.c_int64(a.numel()), L.ptr(y), L.stream())
+    return y

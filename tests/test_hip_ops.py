@@ -1,0 +1,187 @@
+"""GPU parity of the non-attention HIP kernels (through the C ABI) against plain
+PyTorch fp32 on the CPU, fed the same bf16-rounded inputs.
+
+Tolerances: bf16 operands, fp32 accumulation.  Outputs stored as bf16 carry a
+2^-9 relative rounding (rel-L2 ~1.5e-3 on its own); asserts use rel-L2 <= 4e-3
+for bf16 outputs and <= 2e-3 for fp32 outputs (statistics, weight gradients).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_fixture, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def cl(t):       # [B,C,H,W,D] -> channels-last bf16 on device
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+
+
+def cf(t):       # channels-last device -> [B,C,H,W,D] float cpu
+    return t.float().cpu().permute(0, 4, 1, 2, 3)
+
+
+@pytest.mark.parametrize("cin,cout,dims,affine,lrelu,res,f32", [
+    (16, 16, (5, 6, 7), False, False, False, False),
+    (24, 48, (6, 6, 8), True, True, False, False),      # Cin % 32 != 0: k-steps straddle taps
+    (64, 64, (4, 4, 6), False, False, True, False),     # bottleneck-style residual
+    (48, 2, (8, 8, 8), True, False, False, True),       # segmentation head: BN prologue, fp32 logits
+    (144, 48, (6, 5, 4), True, True, False, False),     # dec2 conv_concat channel counts
+    (8, 96, (3, 3, 3), False, False, False, False),
+])
+def test_conv3d_fwd(cin, cout, dims, affine, lrelu, res, f32):
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = r16(torch.randn(2, cin, *dims, generator=g))
+    w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    scale = 1 + 0.2 * torch.randn(cin, generator=g) if affine else None
+    shift = 0.2 * torch.randn(cin, generator=g) if affine else None
+    resid = r16(torch.randn(2, cout, *dims, generator=g)) if res else None
+    xin = x
+    if affine:
+        xin = x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+        if lrelu:
+            xin = F.leaky_relu(xin, 0.01)
+        xin = r16(xin)
+    want = F.conv3d(xin, w, b, padding=1)
+    if res:
+        want = want + resid
+    wp = ops.pack_conv_weight(w.to(DEV))
+    y = ops.conv3d(cl(x), wp, b.to(DEV), cout, None if scale is None else scale.to(DEV),
+                   None if shift is None else shift.to(DEV), lrelu, None if resid is None else cl(resid), f32)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want) < (2e-3 if f32 else 4e-3)
+
+
+def test_conv3d_dgrad_and_head_wgrad():
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    cin, cout, dims = 48, 2, (6, 8, 8)
+    x = r16(torch.randn(2, cin, *dims, generator=g)).requires_grad_(True)
+    w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    scale = 1 + 0.2 * torch.randn(cin, generator=g)
+    shift = 0.2 * torch.randn(cin, generator=g)
+    xin = r16((x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)).detach()).requires_grad_(True)
+    y = F.conv3d(xin, w, b, padding=1)
+    dy = r16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    # data gradient = same kernel with flipped / transposed weights; dy carries 8 channels (6 zero)
+    wd, cpad = ops.pack_conv_weight_dgrad(w.detach().to(DEV))
+    dyp = torch.zeros(2, *dims, cpad, dtype=torch.bfloat16, device=DEV)
+    dyp[..., :cout] = cl(dy)
+    dx = ops.conv3d(dyp, wd, None, cin)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(dx), xin.grad) < 4e-3
+    dw, db = ops.conv3d_wgrad_small(cl(x.detach()), scale.to(DEV), shift.to(DEV), False, dyp, cout)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu(), w.grad) < 2e-3
+    assert rel_l2(db.cpu(), b.grad) < 2e-3
+
+
+@pytest.mark.parametrize("C,dims", [(48, (6, 6, 6)), (144, (4, 5, 6)), (8, (3, 3, 2))])
+def test_batchnorm_train_fwd_bwd(C, dims):
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = r16(torch.randn(2, C, *dims, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.leaky_relu(F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5), 0.01)
+    dy = r16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xd = cl(x.detach())
+    scale, shift, mr = ops.bn_batch_stats(xd, w.detach().to(DEV), b.detach().to(DEV), 1e-5, rmd, rvd)
+    yd = ops.affine_act(xd, scale, shift, True)
+    dx, dg, dbeta = ops.bn_backward(xd, cl(dy), scale, shift, mr, True)
+    torch.cuda.synchronize()
+    assert rel_l2(rmd.cpu(), rm) < 1e-4 and rel_l2(rvd.cpu(), rv) < 1e-4
+    assert rel_l2(cf(yd), y) < 4e-3
+    assert rel_l2(cf(dx), x.grad) < 6e-3
+    assert rel_l2(dg.cpu(), w.grad) < 3e-3
+    assert rel_l2(dbeta.cpu(), b.grad) < 3e-3
+
+
+@pytest.mark.parametrize("cin,dims", [(1, (16, 16, 16)), (4, (8, 12, 8))])
+def test_patch_embed(cin, dims):
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin)
+    C = 48
+    x = torch.rand(2, cin, *dims, generator=g)
+    w = torch.randn(C, cin, 2, 2, 2, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    bw, bb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    want = F.batch_norm(F.conv3d(x, w, b, stride=2), rm, rv, bw, bb, True, 0.1, 1e-6)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = ops.patch_embed(x.to(DEV), w.to(DEV), b.to(DEV), bw.to(DEV), bb.to(DEV), 1e-6, rmd, rvd)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want) < 4e-3
+    assert rel_l2(rmd.cpu(), rm) < 1e-4 and rel_l2(rvd.cpu(), rv) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["even_T", "odd_T", "even_F", "odd_F"])
+def test_patch_merge_golden(tag):
+    from mivp_amd import ops
+    from oracle import swin_ref as S
+    fx = load_fixture(f"merge_{tag}")
+    sd = dict(fx["sd"])
+    sd["reduction.weight"] = r16(sd["reduction.weight"])
+    x = r16(fx["in"]["x"])
+    want = S.patch_merge(x, sd, "", fx.meta["merge_last_dim"])
+    y = ops.patch_merge(cl(x), sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV),
+                        sd["reduction.weight"].to(DEV, torch.bfloat16), fx.meta["merge_last_dim"])
+    torch.cuda.synchronize()
+    assert cf(y).shape == want.shape
+    assert rel_l2(cf(y), want) < 5e-3
+
+
+@pytest.mark.parametrize("C,dims,last", [(48, (8, 8, 8), True), (96, (6, 6, 8), False), (192, (4, 6, 5), False)])
+def test_patch_merge_real_channels(C, dims, last):
+    from mivp_amd import ops
+    from oracle import swin_ref as S
+    g = torch.Generator().manual_seed(C)
+    k = 8 if last else 4
+    sd = {"norm.weight": 1 + 0.2 * torch.randn(k * C, generator=g), "norm.bias": 0.1 * torch.randn(k * C, generator=g),
+          "reduction.weight": r16(torch.randn(2 * C, k * C, generator=g) / (k * C) ** 0.5)}
+    x = r16(torch.randn(2, C, *dims, generator=g))
+    want = S.patch_merge(x, sd, "", last)
+    y = ops.patch_merge(cl(x), sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV),
+                        sd["reduction.weight"].to(DEV, torch.bfloat16), last)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want) < 5e-3
+
+
+@pytest.mark.parametrize("idims,sdims,scale,cx,cs", [
+    ((3, 3, 4), (6, 6, 4), (2, 2, 1), 16, 8),
+    ((3, 4, 2), (5, 7, 4), (2, 2, 2), 16, 8),          # skip smaller than 2x: crop
+    ((6, 6, 6), None, (2, 2, 2), 48, 0),               # output layer: plain upsample
+])
+def test_upcat_fwd_bwd(idims, sdims, scale, cx, cs):
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cx + cs)
+    x = r16(torch.randn(2, cx, *idims, generator=g)).requires_grad_(True)
+    up = F.interpolate(x, scale_factor=tuple(float(s) for s in scale), mode="trilinear", align_corners=False)
+    skip = None
+    if cs:
+        skip = r16(torch.randn(2, cs, *sdims, generator=g)).requires_grad_(True)
+        want = torch.cat([up[..., :sdims[0], :sdims[1], :sdims[2]], skip], 1)
+    else:
+        want = up
+    dy = r16(torch.randn(want.shape, generator=g))
+    want.backward(dy)
+    y = ops.upcat(cl(x.detach()), None if skip is None else cl(skip.detach()), scale)
+    dx, dskip = ops.upcat_backward(cl(dy), idims, scale, cx, cs)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want) < 4e-3
+    assert rel_l2(cf(dx), x.grad) < 4e-3
+    if cs:
+        assert rel_l2(cf(dskip), skip.grad) < 1e-6
