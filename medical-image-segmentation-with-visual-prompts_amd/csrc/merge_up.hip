@@ -309,3 +309,120 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
     }
     return MIVP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// K4 backward: dy [T][Cout] -> dx.  dYn = dy W (A = W^T rows = concat channel) -> LayerNorm
+// backward over the kC-long gathered row -> scatter to the 8 (4) source voxels.  The kC-long row
+// does not fit in registers next to the MFMA operands, so the row is walked three times
+// (statistics; LN-backward sums; write) and the dYn tiles are recomputed in the last walk.
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const bf16_t* __restrict__ dy,
+                                                         const bf16_t* __restrict__ x, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, const bf16_t* __restrict__ w_t,
+                                                         bf16_t* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, Cout = d.Cout;
+    const int kC = (d.merge_last ? 8 : 4) * C;
+    const int n_ct = (kC + 15) / 16;
+    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
+    const MergeTok m = merge_token(d, t);
+
+    bf16x8 dyb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = 32 * s + 8 * g;
+        dyb[s] = (m.live && c < Cout) ? ld8(dy + t * Cout + c) : zero8();
+    }
+    auto load_x4 = [&](int c0, long& src_out) -> f32x4 {
+        f32x4 v = fzero4();
+        src_out = -1;
+        if (m.live && c0 < kC) {
+            const int part = c0 / C, ch = c0 - part * C;
+            const long src = merge_src(d, m, part);
+            if (src >= 0) {
+                const bf16x4 raw = ld4(x + src * C + ch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (float)raw[j];
+                src_out = src * C + ch;
+            }
+        }
+        return v;
+    };
+    float sum = 0.f;
+    for (int ct = 0; ct < n_ct; ++ct) { long so; const f32x4 v = load_x4(16 * ct + 4 * g, so); sum += v[0] + v[1] + v[2] + v[3]; }
+    const float mean = col_sum(sum) / (float)kC;
+    float var = 0.f;
+    for (int ct = 0; ct < n_ct; ++ct) {
+        long so;
+        const int c0 = 16 * ct + 4 * g;
+        const f32x4 v = load_x4(c0, so);
+        if (c0 < kC) for (int j = 0; j < 4; ++j) { const float dv = v[j] - mean; var += dv * dv; }
+    }
+    const float rstd = rsqrtf(col_sum(var) / (float)kC + d.ln_eps);
+
+    auto dyn_tile = [&](int ct) -> f32x4 {
+        f32x4 acc = fzero4();
+        const int row = 16 * ct + r;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (row < kC && c < Cout) a = ld8(w_t + (long)row * Cout + c);
+            acc = mfma16(a, dyb[s], acc);
+        }
+        return acc;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int ct = 0; ct < n_ct; ++ct) {
+        const f32x4 gy = dyn_tile(ct);
+        const int c0 = 16 * ct + 4 * g;
+        long so;
+        const f32x4 v = load_x4(c0, so);
+        if (c0 < kC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dxh = gy[j] * ln_w[c0 + j];
+                s1 += dxh;
+                s2 += dxh * (v[j] - mean) * rstd;
+            }
+        }
+    }
+    const float m1 = col_sum(s1) / (float)kC, m2 = col_sum(s2) / (float)kC;
+    for (int ct = 0; ct < n_ct; ++ct) {
+        const f32x4 gy = dyn_tile(ct);
+        const int c0 = 16 * ct + 4 * g;
+        long so;
+        const f32x4 v = load_x4(c0, so);
+        if (c0 < kC && so >= 0) {
+            f32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = rstd * (gy[j] * ln_w[c0 + j] - m1 - (v[j] - mean) * rstd * m2);
+            st4(dx + so, pack4(out));
+        }
+    }
+}
+
+extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
+                                    const float* ln_b, const void* w_t, void* dx, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && dy && x && ln_w && ln_b && w_t && dx);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->Cout % 8 == 0);
+    const int NS = (d->Cout + 31) / 32;
+    const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_MB(K) hipLaunchKernelGGL((k_patch_merge_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, \
+                                         (const bf16_t*)x, ln_w, ln_b, (const bf16_t*)w_t, (bf16_t*)dx)
+    switch (NS) {
+        case 1: LAUNCH_MB(1); break;
+        case 2: LAUNCH_MB(2); break;
+        case 3: LAUNCH_MB(3); break;
+        case 4: LAUNCH_MB(4); break;
+        case 6: LAUNCH_MB(6); break;
+        case 12: LAUNCH_MB(12); break;
+        default: mivp_set_error("patch_merge_bwd: Cout/32 not in {1,2,3,4,6,12}"); return MIVP_EUNSUPPORTED;
+    }
+#undef LAUNCH_MB
+    return mivp_check_launch("patch_merge_bwd");
+}

@@ -1,0 +1,838 @@
+// Swin block backward: data gradients (dx) and the prompt-token / prompt-bias gradients.
+// Mirrors swin_fwd.hip stage by stage; reference semantics as there (swin_block.py:145-255,
+// window_attention.py:35-61).  Attention backward recomputes P from q, k and the saved
+// log-sum-exp (flash-style), in two owner passes:
+//   dq  pass: one wave owns 16 queries, walks all keys   (S^T = K' Q'^T : query on the lane)
+//   dkv pass: one wave owns 16 keys,    walks all queries (S   = Q' K'^T : key on the lane)
+// so every reduction a wave needs is over the MFMA row index of its own accumulators and the
+// probabilities feed the next MFMA without leaving their lanes (common.hpp convention).
+#include "common.hpp"
+
+int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
+
+namespace {
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct TokInfo { long tt, bp, b; int slot, pw; bool live; };
+
+MIVP_DEV TokInfo token_info(const MivpSwinDesc& d, long t) {
+    TokInfo ti;
+    const long T = (long)d.B * d.P * d.Nqp;
+    ti.live = t < T;
+    ti.tt = ti.live ? t : 0;
+    ti.bp = ti.tt / d.Nqp;
+    ti.slot = (int)(ti.tt - ti.bp * d.Nqp);
+    ti.pw = (int)(ti.bp % d.P);
+    ti.b = ti.bp / d.P;
+    return ti;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// proj + MLP backward:  dy -> (dO, dt1)
+//   t2 = t1 + Linear(LN(t1)) ; t1 = proj(O) + b + t0
+//   dh  = dt2 Wmlp            (A = Wmlp^T rows = input channel)
+//   dt1 = dt2 + LNbwd(dh ; t1) ; dO = dt1 Wproj
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dy,
+                                                           const int* __restrict__ tok_dst, const bf16_t* __restrict__ t1,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                           const bf16_t* __restrict__ wmlp_t, const bf16_t* __restrict__ wproj_t,
+                                                           bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1) {
+    constexpr int KS = (CT + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C;
+    const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);
+    const int dst = ti.live ? tok_dst[ti.pw * d.Nqp + ti.slot] : -1;
+    const bf16_t* dyrow = dy + (ti.b * d.vol_out + (dst >= 0 ? dst : 0)) * (long)C;
+
+    bf16x8 dyb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+        dyb[s] = (dst >= 0 && c < C) ? ld8(dyrow + c) : zero8();
+    }
+    f32x4 dh[CT], tv[CT];
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4 acc = fzero4();
+        const int row = 16 * ct + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (row < C && c < C) a = ld8(wmlp_t + (long)row * C + c);
+            acc = mfma16(a, dyb[s], acc);
+        }
+        dh[ct] = acc;
+        const int n0 = 16 * ct + 4 * g;
+        f32x4 v = fzero4();
+        if (ti.live && n0 < C) { const bf16x4 raw = ld4(t1 + ti.tt * (long)C + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
+        tv[ct] = v;
+        sum += v[0] + v[1] + v[2] + v[3];
+    }
+    const float mean = col_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+        if (16 * ct + 4 * g < C)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dv = tv[ct][j] - mean; var += dv * dv; }
+    const float rstd = rsqrtf(col_sum(var) / (float)C + d.ln_eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int n0 = 16 * ct + 4 * g;
+        if (n0 < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dxh = dh[ct][j] * ln_w[n0 + j];
+                const float xh = (tv[ct][j] - mean) * rstd;
+                dh[ct][j] = dxh;
+                tv[ct][j] = xh;
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        }
+    }
+    const float m1 = col_sum(s1) / (float)C, m2 = col_sum(s2) / (float)C;
+    bf16x4 g1[2 * KS];
+#pragma unroll
+    for (int ct = 0; ct < 2 * KS; ++ct) {
+        bf16x4 out = zero4();
+        if (ct < CT) {
+            const int n0 = 16 * ct + 4 * g;
+            if (n0 < C) {
+                f32x4 v = fzero4();
+                if (dst >= 0) { const bf16x4 raw = ld4(dyrow + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rstd * (dh[ct][j] - m1 - tv[ct][j] * m2);
+                out = pack4(v);
+                if (ti.live) st4(d_t1 + ti.tt * (long)C + n0, out);
+            }
+        }
+        g1[ct] = out;
+    }
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt) {
+        f32x4 acc = fzero4();
+        const int row = 16 * mt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x4 lo = zero4(), hi = zero4();
+            const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
+            if (row < C) {
+                if (c0 < C) lo = ld4(wproj_t + (long)row * C + c0);
+                if (c1 < C) hi = ld4(wproj_t + (long)row * C + c1);
+            }
+            acc = mfma16(cat44(lo, hi), cat44(g1[2 * s], g1[2 * s + 1]), acc);
+        }
+        const int n0 = 16 * mt + 4 * g;
+        if (ti.live && n0 < C) st4(d_o + ti.tt * (long)C + n0, pack4(acc));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// delta[bp][head][q] = sum_j dO * O over the head's channels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_win_attn_delta(MivpSwinDesc d, const bf16_t* __restrict__ o,
+                                                        const bf16_t* __restrict__ d_o, float* __restrict__ delta) {
+    const int hd = d.C / d.heads;
+    const long total = (long)d.B * d.P * d.heads * d.Nqp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int qrow = (int)(i % d.Nqp);
+        const long bph = i / d.Nqp;
+        const int head = (int)(bph % d.heads);
+        const long bp = bph / d.heads;
+        const long off = (bp * d.Nqp + qrow) * (long)d.C + head * hd;
+        float acc = 0.f;
+        for (int j = 0; j < hd; j += 4) {
+            const bf16x4 a = ld4(o + off + j), b = ld4(d_o + off + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += (float)a[e] * (float)b[e];
+        }
+        delta[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dq pass.  grid = (B*P*heads, ceil(Nqp/64)); wave w owns query tile 4*blockIdx.y + w.
+// Keys are staged chunk by chunk: K' rows (S), V rows padded to 32 columns (dP), K^T (dq).
+// ---------------------------------------------------------------------------------------------
+template <int DKS, int DVT>
+__global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
+                                                         const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                         const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
+                                                         const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
+                                                         const int* __restrict__ tok_rid, const bf16_t* __restrict__ d_o,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         bf16_t* __restrict__ dq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DK = 32 * DKS, DVS = (DVT + 1) / 2, DVP = 32 * DVS;
+    constexpr int KROW = (DK + 8) * 2, VROWB = (DVP + 8) * 2;
+    const int ckeys = chunk_tiles * 16;
+    const int KTROW = (ckeys + 8) * 2;
+    char* Kimg = smem;
+    char* Vimg = Kimg + (size_t)ckeys * KROW;
+    char* Kt = Vimg + (size_t)ckeys * VROWB;
+    int* ridk = reinterpret_cast<int*>(Kt + (size_t)(16 * DVT) * KTROW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
+    const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4, dvp4 = DVP / 4;
+    const long bph = blockIdx.x;
+    const int head = (int)(bph % heads);
+    const long bp = bph / heads;
+    const int pw = (int)(bp % d.P);
+    const int qt = 4 * blockIdx.y + wave;
+    const bool qlive = qt * 16 < Nqp;
+    const int qrow = qlive ? qt * 16 + r : 0;
+
+    // per-query state (lane r)
+    const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+    const float lse_b = lse[bph * Nqp + qrow] * LOG2E;
+    const float dl = delta[bph * Nqp + qrow];
+    bf16x8 qf[DKS], dof[DVS];
+#pragma unroll
+    for (int s = 0; s < DKS; ++s) {
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 8 * s + 2 * g + hlf;
+            bf16x4 val = zero4();
+            if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
+            else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
+            piece[hlf] = val;
+        }
+        qf[s] = cat44(piece[0], piece[1]);
+    }
+#pragma unroll
+    for (int s = 0; s < DVS; ++s) {
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 8 * s + 2 * g + hlf;
+            piece[hlf] = c4 < hd4 ? ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4)) : zero4();
+        }
+        dof[s] = cat44(piece[0], piece[1]);
+    }
+    f32x4 dqacc[DVT];
+#pragma unroll
+    for (int dd = 0; dd < DVT; ++dd) dqacc[dd] = fzero4();
+
+    const int nt = Nkp / 16;
+    const int nt_full = d.Nq / 16;
+    for (int t0 = 0; t0 < nt; t0 += chunk_tiles) {
+        const int ntc = (nt - t0) < chunk_tiles ? (nt - t0) : chunk_tiles;       // tiles in this chunk (even)
+        const int key0 = t0 * 16, nkeys = ntc * 16;
+        __syncthreads();
+        for (int e = tid; e < nkeys * dk4; e += 256) {
+            const int lrow = e / dk4, c4 = e - lrow * dk4, row = key0 + lrow;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (row < Nqp) val = ld4(k + ((bph * Nqp + row) * (long)hd + 4 * c4));
+                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+                if (c4 < 4 * DVT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
+                }
+            } else if (c4 < hd4 + a4) {
+                val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
+            }
+            *reinterpret_cast<bf16x4*>(Kimg + (size_t)lrow * KROW + 8 * c4) = val;
+        }
+        // K^T rows between hd and 16*DVT must be zero (they multiply dS in the dq MFMA)
+        for (int e = tid; e < (16 * DVT - hd) * nkeys; e += 256) {
+            const int rr = hd + e / nkeys, col = e % nkeys;
+            *reinterpret_cast<bf16_t*>(Kt + (size_t)rr * KTROW + 2 * col) = (bf16_t)0.0f;
+        }
+        for (int e = tid; e < nkeys * dvp4; e += 256) {
+            const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = key0 + lrow;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
+                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+            }
+            *reinterpret_cast<bf16x4*>(Vimg + (size_t)lrow * VROWB + 8 * c4) = val;
+        }
+        for (int m = tid; m < nkeys; m += 256) {
+            const int row = key0 + m;
+            int cls = -1;
+            if (row < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + row] : 0;
+            else if (row >= Nqp && row < Nqp + d.Np) cls = -2;
+            ridk[m] = cls;
+        }
+        __syncthreads();
+        if (!qlive) continue;
+        for (int u = 0; u < ntc / 2; ++u) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int lt = 2 * u + hh;
+                f32x4 s = fzero4(), dp = fzero4();
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks)
+                    s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * lt + r) * KROW + (32 * ks + 8 * g) * 2), qf[ks], s);
+#pragma unroll
+                for (int ks = 0; ks < DVS; ++ks)
+                    dp = mfma16(*reinterpret_cast<const bf16x8*>(Vimg + (size_t)(16 * lt + r) * VROWB + (32 * ks + 8 * g) * 2), dof[ks], dp);
+                const int4 kr4 = *reinterpret_cast<const int4*>(ridk + 16 * lt + 4 * g);
+                const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+                const bool fast = (t0 + lt) < nt_full && !d.has_mask;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sv = s[j];
+                    bool grad = true;
+                    if (!fast) {
+                        if (krs[j] == -1) { sv = -INFINITY; grad = false; }
+                        else if (krs[j] != -2 && krs[j] != rq) { sv = 0.f; grad = false; }
+                    }
+                    const float p = __builtin_amdgcn_exp2f(sv * LOG2E - lse_b);
+                    ds[hh][j] = grad ? p * (dp[j] - dl) : 0.f;
+                }
+            }
+            const bf16x8 pb = cat44(pack4(ds[0]), pack4(ds[1]));
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd) {
+                const char* krow = Kt + (size_t)(16 * dd + r) * KTROW;
+                const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(krow + (32 * u + 4 * g) * 2),
+                                       *reinterpret_cast<const bf16x4*>(krow + (32 * u + 16 + 4 * g) * 2));
+                dqacc[dd] = mfma16(a, pb, dqacc[dd]);
+            }
+        }
+    }
+    if (qlive) {
+#pragma unroll
+        for (int dd = 0; dd < DVT; ++dd) {
+            const int j0 = 16 * dd + 4 * g;
+            if (j0 < hd) st4(dq + ((bph * Nqp + qrow) * (long)hd + j0), pack4(dqacc[dd]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dkv pass.  grid = (B*P*heads, key-tile groups); wave w owns key tile kt0 + 4*blockIdx.y + w.
+// Queries are staged chunk by chunk: Q' rows (S), dO rows padded to 32 columns (dP), Q^T (dk),
+// dO^T (dv), log-sum-exp, delta, query region ids.
+// Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
+// gradient of the prompt-token bias score).
+// ---------------------------------------------------------------------------------------------
+template <int DKS, int DVT>
+__global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
+                                                          const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                          const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
+                                                          const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
+                                                          const bf16_t* __restrict__ ka, const int* __restrict__ tok_rid,
+                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dk,
+                                                          bf16_t* __restrict__ dv, float* __restrict__ dkp_part,
+                                                          float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DK = 32 * DKS, DVS = (DVT + 1) / 2, DVP = 32 * DVS;
+    constexpr int QROW = (DK + 8) * 2, OROW = (DVP + 8) * 2;
+    const int cq = chunk_tiles * 16;
+    const int TROW = (cq + 8) * 2;
+    char* Qimg = smem;
+    char* Oimg = Qimg + (size_t)cq * QROW;
+    char* Qt = Oimg + (size_t)cq * OROW;
+    char* Ot = Qt + (size_t)(16 * DVT) * TROW;
+    float* lse_s = reinterpret_cast<float*>(Ot + (size_t)(16 * DVT) * TROW);
+    float* del_s = lse_s + cq;
+    int* ridq = reinterpret_cast<int*>(del_s + cq);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
+    const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4, dvp4 = DVP / 4;
+    const long bph = blockIdx.x;
+    const int head = (int)(bph % heads);
+    const long bp = bph / heads;
+    const int pw = (int)(bp % d.P);
+    const int kt = kt0 + 4 * blockIdx.y + wave;
+    const bool klive = kt * 16 < Nkp;
+    const int krow = klive ? kt * 16 + r : 0;
+
+    // per-key state (lane r)
+    int kcls = -1;
+    if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
+    else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
+    const bool is_prompt = krow >= Nqp;
+    bf16x8 kf[DKS], vf[DVS];
+#pragma unroll
+    for (int s = 0; s < DKS; ++s) {
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 8 * s + 2 * g + hlf;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (krow < Nqp) val = ld4(k + ((bph * Nqp + krow) * (long)hd + 4 * c4));
+                else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
+            } else if (c4 < hd4 + a4) {
+                val = ld4(ka + (((long)head * Nkp + krow) * A + 4 * (c4 - hd4)));
+            }
+            piece[hlf] = val;
+        }
+        kf[s] = cat44(piece[0], piece[1]);
+    }
+#pragma unroll
+    for (int s = 0; s < DVS; ++s) {
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 8 * s + 2 * g + hlf;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (krow < Nqp) val = ld4(v + ((bph * Nqp + krow) * (long)hd + 4 * c4));
+                else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
+            }
+            piece[hlf] = val;
+        }
+        vf[s] = cat44(piece[0], piece[1]);
+    }
+    f32x4 dkacc[DVT], dvacc[DVT];
+#pragma unroll
+    for (int dd = 0; dd < DVT; ++dd) { dkacc[dd] = fzero4(); dvacc[dd] = fzero4(); }
+    float dtok = 0.f;
+
+    const int nqt = (Nqp + 31) / 32 * 2;                      // query tiles rounded to pairs
+    for (int t0 = 0; t0 < nqt; t0 += chunk_tiles) {
+        const int ntc = (nqt - t0) < chunk_tiles ? (nqt - t0) : chunk_tiles;
+        const int q0 = t0 * 16, nq = ntc * 16;
+        __syncthreads();
+        for (int e = tid; e < nq * dk4; e += 256) {
+            const int lrow = e / dk4, c4 = e - lrow * dk4, row = q0 + lrow;
+            bf16x4 val = zero4();
+            if (row < Nqp) {
+                if (c4 < hd4) val = ld4(q + ((bph * Nqp + row) * (long)hd + 4 * c4));
+                else if (c4 < hd4 + a4) val = ld4(qa + ((long)row * A + 4 * (c4 - hd4)));
+            }
+            if (c4 < 4 * DVT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<bf16_t*>(Qt + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = (c4 < hd4) ? val[i] : (bf16_t)0.0f;
+            }
+            *reinterpret_cast<bf16x4*>(Qimg + (size_t)lrow * QROW + 8 * c4) = val;
+        }
+        for (int e = tid; e < nq * dvp4; e += 256) {
+            const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
+            bf16x4 val = zero4();
+            if (row < Nqp && c4 < hd4) val = ld4(d_o + ((bp * Nqp + row) * (long)C + head * hd + 4 * c4));
+            if (c4 < 4 * DVT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Ot + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = val[i];
+            }
+            *reinterpret_cast<bf16x4*>(Oimg + (size_t)lrow * OROW + 8 * c4) = val;
+        }
+        for (int m = tid; m < nq; m += 256) {
+            const int row = q0 + m;
+            const bool ok = row < Nqp;
+            lse_s[m] = ok ? lse[bph * Nqp + row] * LOG2E : 0.f;
+            del_s[m] = ok ? delta[bph * Nqp + row] : 0.f;
+            ridq[m] = (ok && row < d.Nq) ? (d.has_mask ? tok_rid[pw * Nqp + row] : 0) : -1;   // -1: padding query row
+        }
+        __syncthreads();
+        if (!klive) continue;
+        for (int u = 0; u < ntc / 2; ++u) {
+            f32x4 pv[2], ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int lt = 2 * u + hh;
+                f32x4 s = fzero4(), dp = fzero4();
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks)
+                    s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + (size_t)(16 * lt + r) * QROW + (32 * ks + 8 * g) * 2), kf[ks], s);
+#pragma unroll
+                for (int ks = 0; ks < DVS; ++ks)
+                    dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
+                // rows of this accumulator tile are queries 16*lt + 4g + j
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
+                const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
+                const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
+                const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sv = s[j];
+                    bool grad = true;
+                    if (kcls == -1) { sv = -INFINITY; grad = false; }
+                    else if (kcls != -2 && kcls != rqs[j]) { sv = 0.f; grad = false; }
+                    float p = __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]);
+                    if (rqs[j] == -1) { p = 0.f; grad = false; }           // padding query rows carry no gradient
+                    pv[hh][j] = p;
+                    const float dsv = grad ? p * (dp[j] - dls[j]) : 0.f;
+                    ds[hh][j] = dsv;
+                    dtok += dsv;
+                }
+            }
+            const bf16x8 pb = cat44(pack4(pv[0]), pack4(pv[1]));
+            const bf16x8 sb = cat44(pack4(ds[0]), pack4(ds[1]));
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd) {
+                const char* qrow_t = Qt + (size_t)(16 * dd + r) * TROW;
+                const char* orow_t = Ot + (size_t)(16 * dd + r) * TROW;
+                const bf16x8 aq = cat44(*reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 4 * g) * 2),
+                                        *reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 16 + 4 * g) * 2));
+                const bf16x8 ao = cat44(*reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 4 * g) * 2),
+                                        *reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 16 + 4 * g) * 2));
+                dkacc[dd] = mfma16(aq, sb, dkacc[dd]);
+                dvacc[dd] = mfma16(ao, pb, dvacc[dd]);
+            }
+        }
+    }
+    if (!klive) return;
+    dtok = col_sum(dtok);
+    if (!is_prompt) {
+        if (dk && dv) {
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd) {
+                const int j0 = 16 * dd + 4 * g;
+                if (j0 < hd) {
+                    st4(dk + ((bph * Nqp + krow) * (long)hd + j0), pack4(dkacc[dd]));
+                    st4(dv + ((bph * Nqp + krow) * (long)hd + j0), pack4(dvacc[dd]));
+                }
+            }
+        }
+    } else if (krow < Nqp + d.Npp) {
+        const int t = krow - Nqp;
+#pragma unroll
+        for (int dd = 0; dd < DVT; ++dd) {
+            const int j0 = 16 * dd + 4 * g;
+            if (j0 < hd) {
+                *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dkacc[dd];
+                *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dvacc[dd];
+            }
+        }
+        if (g == 0) dtok_part[bph * d.Npp + t] = dtok;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QKV + LayerNorm + gather backward:  (dq, dk, dv, dt1) -> dx
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dq,
+                                                      const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
+                                                      const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
+                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                      const bf16_t* __restrict__ wqkv_t, const bf16_t* __restrict__ d_t1,
+                                                      bf16_t* __restrict__ dx) {
+    constexpr int KS3 = (3 * 16 * CT + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, hd = C / d.heads, n3 = 3 * C;
+    const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);
+    const int src = ti.live ? tok_src[ti.pw * d.Nqp + ti.slot] : -2;
+
+    bf16x8 gb[KS3];
+#pragma unroll
+    for (int s = 0; s < KS3; ++s) {
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int n0 = 32 * s + 8 * g + 4 * hlf;
+            bf16x4 val = zero4();
+            if (ti.live && n0 < n3) {
+                const int sel = n0 / C, cc = n0 - sel * C, head = cc / hd, j0 = cc - head * hd;
+                const bf16_t* base = sel == 0 ? dq : (sel == 1 ? dk : dv);
+                val = ld4(base + ((ti.bp * d.heads + head) * d.Nqp + ti.slot) * (long)hd + j0);
+                if (sel == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) val[j] = (bf16_t)((float)val[j] * d.q_scale);
+                }
+            }
+            piece[hlf] = val;
+        }
+        gb[s] = cat44(piece[0], piece[1]);
+    }
+    f32x4 dyv[CT], xv[CT];
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4 acc = fzero4();
+        const int row = 16 * ct + r;
+#pragma unroll
+        for (int s = 0; s < KS3; ++s) {
+            const int n0 = 32 * s + 8 * g;
+            bf16x8 a = zero8();
+            if (row < C && n0 < n3) a = ld8(wqkv_t + (long)row * n3 + n0);
+            acc = mfma16(a, gb[s], acc);
+        }
+        dyv[ct] = acc;
+        const int c0 = 16 * ct + 4 * g;
+        f32x4 xx = fzero4();
+        if (src >= 0 && c0 < C) { const bf16x4 raw = ld4(x + ((ti.b * d.vol_in + src) * (long)C + c0)); for (int j = 0; j < 4; ++j) xx[j] = (float)raw[j]; }
+        xv[ct] = xx;
+        sum += xx[0] + xx[1] + xx[2] + xx[3];
+    }
+    const float mean = col_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+        if (16 * ct + 4 * g < C)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dvv = xv[ct][j] - mean; var += dvv * dvv; }
+    const float rstd = rsqrtf(col_sum(var) / (float)C + d.ln_eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c0 = 16 * ct + 4 * g;
+        if (c0 < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dxh = dyv[ct][j] * ln_w[c0 + j];
+                const float xh = (xv[ct][j] - mean) * rstd;
+                dyv[ct][j] = dxh;
+                xv[ct][j] = xh;
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        }
+    }
+    const float m1 = col_sum(s1) / (float)C, m2 = col_sum(s2) / (float)C;
+    if (src < 0) return;                       // zero-pad / padding-slot tokens have no voxel to write
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c0 = 16 * ct + 4 * g;
+        if (c0 < C) {
+            const bf16x4 raw = ld4(d_t1 + ti.tt * (long)C + c0);
+            f32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = (float)raw[j] + rstd * (dyv[ct][j] - m1 - xv[ct][j] * m2);
+            st4(dx + ((ti.b * d.vol_in + src) * (long)C + c0), pack4(out));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prompt K/V backward: (dKp, dVp) -> to_k / to_v -> LayerNorm backward -> dprompt   (64 rows: VALU)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prompt_kv_bwd(MivpSwinDesc d, const float* __restrict__ dkp,
+                                                       const float* __restrict__ dvp, const float* __restrict__ prompt,
+                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                       const bf16_t* __restrict__ wqkv, float* __restrict__ dprompt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gk = reinterpret_cast<float*>(smem);            // [C] dK row (head-merged)
+    float* gv = gk + d.C;                                    // [C]
+    float* red = gv + d.C;                                   // [16]
+    const int t = blockIdx.x, C = d.C, hd = C / d.heads, tid = threadIdx.x;
+    for (int n = tid; n < C; n += 256) {
+        const int head = n / hd, j = n - head * hd;
+        gk[n] = dkp[((long)head * d.Npp + t) * hd + j];
+        gv[n] = dvp[((long)head * d.Npp + t) * hd + j];
+    }
+    // LayerNorm statistics of the prompt row
+    float part = 0.f;
+    for (int c = tid; c < C; c += 256) part += prompt[(long)t * C + c];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    part = 0.f;
+    for (int c = tid; c < C; c += 256) { const float dvv = prompt[(long)t * C + c] - mean; part += dvv * dvv; }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = part;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + d.ln_eps);
+    // dy[c] = sum_n gk[n] Wk[n][c] + gv[n] Wv[n][c] ; then LN backward (each thread owns channels c, c+256, ...)
+    float s1 = 0.f, s2 = 0.f;
+    float dxh_loc[4], xh_loc[4];
+    int cnt = 0;
+    for (int c = tid; c < C; c += 256, ++cnt) {
+        float acc = 0.f;
+        for (int n = 0; n < C; ++n)
+            acc += gk[n] * (float)wqkv[(long)(C + n) * C + c] + gv[n] * (float)wqkv[(long)(2 * C + n) * C + c];
+        const float dxh = acc * ln_w[c];
+        const float xh = (prompt[(long)t * C + c] - mean) * rstd;
+        dxh_loc[cnt] = dxh;
+        xh_loc[cnt] = xh;
+        s1 += dxh;
+        s2 += dxh * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[8 + (tid >> 6)] = s1; red[12 + (tid >> 6)] = s2; }
+    __syncthreads();
+    const float m1 = (red[8] + red[9] + red[10] + red[11]) / (float)C;
+    const float m2 = (red[12] + red[13] + red[14] + red[15]) / (float)C;
+    cnt = 0;
+    for (int c = tid; c < C; c += 256, ++cnt) dprompt[(long)t * C + c] = rstd * (dxh_loc[cnt] - m1 - xh_loc[cnt] * m2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int bwd_checks(const MivpSwinDesc* d) {
+    MIVP_REQUIRE(d != nullptr);
+    MIVP_REQUIRE(d->B > 0 && d->C > 0 && d->heads > 0 && d->P > 0);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->C % d->heads == 0 && (d->C / d->heads) % 4 == 0);
+    MIVP_REQUIRE(d->Nqp % 16 == 0 && d->Npp % 16 == 0 && d->Nkp % 32 == 0 && d->augp % 4 == 0);
+    return MIVP_OK;
+}
+
+#define CT_SWITCH(CTV, LAUNCH)                                                              \
+    switch (CTV) {                                                                          \
+        case 1: LAUNCH(1); break;                                                           \
+        case 2: LAUNCH(2); break;                                                           \
+        case 3: LAUNCH(3); break;                                                           \
+        case 4: LAUNCH(4); break;                                                           \
+        case 6: LAUNCH(6); break;                                                           \
+        case 8: LAUNCH(8); break;                                                           \
+        case 12: LAUNCH(12); break;                                                         \
+        default: mivp_set_error("C/16 not in {1,2,3,4,6,8,12}"); return MIVP_EUNSUPPORTED; \
+    }
+
+extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
+                                      const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
+                                      void* d_o, void* d_t1, mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(dy && tok_dst && t1 && ln_w && ln_b && wmlp_t && wproj_t && d_o && d_t1);
+    const long T = (long)d->B * d->P * d->Nqp;
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define L_PMB(K) hipLaunchKernelGGL((k_swin_proj_mlp_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, tok_dst, \
+                                     (const bf16_t*)t1, ln_w, ln_b, (const bf16_t*)wmlp_t, (const bf16_t*)wproj_t,          \
+                                     (bf16_t*)d_o, (bf16_t*)d_t1)
+    CT_SWITCH((d->C + 15) / 16, L_PMB)
+#undef L_PMB
+    return mivp_check_launch("swin_proj_mlp_bwd");
+}
+
+extern "C" int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
+                                   mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(o && d_o && delta);
+    const long total = (long)d->B * d->P * d->heads * d->Nqp;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_win_attn_delta, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)o,
+                       (const bf16_t*)d_o, delta);
+    return mivp_check_launch("win_attn_delta");
+}
+
+static int pick_chunk(int total_tiles, size_t fixed_bytes, size_t bytes_per_tile, size_t budget) {
+    int c = (int)((budget - fixed_bytes) / bytes_per_tile);
+    c &= ~1;
+    if (c > total_tiles) c = total_tiles;
+    if (c < 2) c = 2;
+    return c;
+}
+
+template <int DKS, int DVT>
+static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
+                     const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
+                     const float* delta, void* dq, hipStream_t st) {
+    constexpr int DK = 32 * DKS, DVP = 32 * ((DVT + 1) / 2);
+    const size_t per_tile = 16 * (size_t)(DK + 8) * 2 + 16 * (size_t)(DVP + 8) * 2 + (size_t)16 * DVT * 32 + 64;
+    const size_t fixed = (size_t)16 * DVT * 16;
+    const int nt = d->Nkp / 16;
+    const int chunk = pick_chunk(nt, fixed, per_tile, 64 * 1024);
+    const size_t lds = fixed + per_tile * chunk;
+    dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)((d->Nqp / 16 + 3) / 4));
+    hipLaunchKernelGGL((k_win_attn_bwd_dq<DKS, DVT>), grid, dim3(256), lds, st, *d, chunk, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid,
+                       (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
+    return mivp_check_launch("win_attn_bwd_dq");
+}
+
+extern "C" int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                                    const void* vp, const void* qa, const void* ka, const int32_t* tok_rid,
+                                    const void* d_o, const float* lse, const float* delta, void* dq,
+                                    mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(q && k && v && qa && ka && d_o && lse && delta && dq);
+    MIVP_REQUIRE(d->Np == 0 || (kp && vp));
+    MIVP_REQUIRE(!d->has_mask || tok_rid);
+    int dks, nt;
+    if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dq: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dks == 1) return launch_dq<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
+    if (dks == 2) return launch_dq<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
+    return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
+}
+
+template <int DKS, int DVT>
+static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
+                      const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
+                      const float* delta, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
+                      hipStream_t st) {
+    constexpr int DK = 32 * DKS, DVP = 32 * ((DVT + 1) / 2);
+    const size_t per_tile = 16 * (size_t)(DK + 8) * 2 + 16 * (size_t)(DVP + 8) * 2 + 2 * (size_t)16 * DVT * 32 + 3 * 64;
+    const size_t fixed = 2 * (size_t)16 * DVT * 16;
+    const int nqt = (d->Nqp + 31) / 32 * 2;
+    const int chunk = pick_chunk(nqt, fixed, per_tile, 64 * 1024);
+    const size_t lds = fixed + per_tile * chunk;
+    const int nt = d->Nkp / 16;
+    const int kt0 = (dk && dv) ? 0 : d->Nqp / 16;            // prompt-only mode skips the window keys
+    const int ktiles = nt - kt0;
+    if (ktiles <= 0) return MIVP_OK;
+    dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)((ktiles + 3) / 4));
+    hipLaunchKernelGGL((k_win_attn_bwd_dkv<DKS, DVT>), grid, dim3(256), lds, st, *d, chunk, kt0, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
+                       (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part,
+                       dvp_part, dtok_part);
+    return mivp_check_launch("win_attn_bwd_dkv");
+}
+
+extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                                     const void* vp, const void* qa, const void* ka, const int32_t* tok_rid,
+                                     const void* d_o, const float* lse, const float* delta, void* dk, void* dv,
+                                     float* dkp_part, float* dvp_part, float* dtok_part, mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(q && k && v && qa && ka && d_o && lse && delta);
+    MIVP_REQUIRE((dk == nullptr) == (dv == nullptr));
+    MIVP_REQUIRE(d->Np == 0 || (kp && vp && dkp_part && dvp_part && dtok_part));
+    MIVP_REQUIRE(!d->has_mask || tok_rid);
+    int dks, nt;
+    if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dks == 1) return launch_dkv<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    if (dks == 2) return launch_dkv<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    return launch_dkv<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+}
+
+extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x,
+                                 const int32_t* tok_src, const float* ln_w, const float* ln_b, const void* wqkv_t,
+                                 const void* d_t1, void* dx, mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(dq && dk && dv && x && tok_src && ln_w && ln_b && wqkv_t && d_t1 && dx);
+    const long T = (long)d->B * d->P * d->Nqp;
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define L_QB(K) hipLaunchKernelGGL((k_swin_qkv_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dq, (const bf16_t*)dk, \
+                                    (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, ln_b, (const bf16_t*)wqkv_t,             \
+                                    (const bf16_t*)d_t1, (bf16_t*)dx)
+    CT_SWITCH((d->C + 15) / 16, L_QB)
+#undef L_QB
+    return mivp_check_launch("swin_qkv_bwd");
+}
+
+extern "C" int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const float* dvp, const float* prompt,
+                                  const float* ln_w, const float* ln_b, const void* wqkv, float* dprompt,
+                                  mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(d->Np > 0 && dkp && dvp && prompt && ln_w && ln_b && wqkv && dprompt);
+    MIVP_REQUIRE(d->C <= 1024);
+    hipLaunchKernelGGL(k_prompt_kv_bwd, dim3(d->Np), dim3(256), (2 * d->C + 16) * sizeof(float), (hipStream_t)stream, *d,
+                       dkp, dvp, prompt, ln_w, ln_b, (const bf16_t*)wqkv, dprompt);
+    return mivp_check_launch("prompt_kv_bwd");
+}
+
+extern "C" int mivp_sizeof_desc(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(MivpSwinDesc);
+        case 1: return (int)sizeof(MivpMergeDesc);
+        case 2: return (int)sizeof(MivpConvDesc);
+        case 3: return (int)sizeof(MivpEmbedDesc);
+        case 4: return (int)sizeof(MivpUpcatDesc);
+        default: return -1;
+    }
+}

@@ -144,6 +144,23 @@ def bn_backward(x, dy, scale, shift, mean_rstd, lrelu):
     return dx, sums[Cc:], sums[:Cc]
 
 
+def bn_backward_eval(x, dy, scale, shift, mean_rstd, lrelu):
+    """Eval-mode BN (running statistics are constants): dx = scale * act'(z) * dy; dgamma/dbeta as in training."""
+    Cc = x.shape[-1]
+    n_vox = x.numel() // Cc
+    nblk = _nblk(n_vox * (Cc // 8), Cc // 8)
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+    L.call("mivp_bn_bwd_stats", L.ptr(x), L.ptr(dy), C.c_int64(n_vox), C.c_int32(Cc), L.ptr(scale), L.ptr(shift),
+           L.ptr(mean_rstd), C.c_int32(1 if lrelu else 0), C.c_int32(nblk), L.ptr(part), L.stream())
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+    L.call("mivp_reduce_rows", L.ptr(part), C.c_int64(nblk), C.c_int64(2 * Cc), L.ptr(sums), L.stream())
+    zeros = torch.zeros_like(sums)
+    dx = torch.empty_like(x)
+    L.call("mivp_bn_bwd_apply", L.ptr(x), L.ptr(dy), C.c_int64(n_vox), C.c_int32(Cc), L.ptr(scale), L.ptr(shift),
+           L.ptr(mean_rstd), L.ptr(zeros), C.c_int32(1 if lrelu else 0), L.ptr(dx), L.stream())
+    return dx, sums[Cc:], sums[:Cc]
+
+
 # ------------------------------------------------------------------------------------------
 # patch embedding (+ its BatchNorm)
 # ------------------------------------------------------------------------------------------
@@ -244,3 +261,13 @@ def add_bf16(a, b):
     y = torch.empty_like(a)
     L.call("mivp_add_bf16", L.ptr(a), L.ptr(b), C.c_int64(a.numel()), L.ptr(y), L.stream())
     return y
+
+
+def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last):
+    B, H, W, D, Cc = x.shape
+    cout = dy.shape[-1]
+    d = merge_desc(B, (H, W, D), Cc, cout, merge_last)
+    dx = torch.empty_like(x)
+    L.call("mivp_patch_merge_bwd", C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w_t_bf16), L.ptr(dx),
+           L.stream())
+    return dx

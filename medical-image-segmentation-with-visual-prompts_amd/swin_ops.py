@@ -96,10 +96,14 @@ class SwinSaved:
     t1: torch.Tensor
 
 
-def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinBlockWeights, window, shift_cfg,
-                       save: bool = False):
-    """x: bf16 [B, H, W, D, C] channels-last; prompt: f32 [Np, C] or None.
-    Returns y (same shape) and, if ``save``, the tensors backward needs."""
+def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinBlockWeights,
+                       ts: Optional[torch.Tensor], window, shift_cfg, save: bool = False):
+    """x: bf16 [B, H, W, D, C] channels-last; prompt: f32 [Np, C] or None; ts: f32 [heads, Np] prompt-token
+    bias scores (``None`` -> ``w.ts``).  Returns y (same shape) and, if ``save``, what backward needs."""
+    if ts is None:
+        ts = w.ts
+    if ts is not None:
+        ts = ts.detach().float().contiguous()
     if x.dtype != BF16 or x.dim() != 5:
         raise RuntimeError("swin_block_forward expects a bf16 [B,H,W,D,C] tensor")
     B, H, W_, D, Cc = x.shape
@@ -124,7 +128,7 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
                L.ptr(kp), L.ptr(vp), L.ptr(None), st)
     qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
     ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
-    L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(w.ts), L.ptr(qa), L.ptr(ka), st)
+    L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(ts), L.ptr(qa), L.ptr(ka), st)
     o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
     lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
     L.call("mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp), L.ptr(qa), L.ptr(ka),
@@ -136,3 +140,66 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     if save:
         return y, SwinSaved(d, tb, x, q, k, v, kp, vp, qa, ka, o, lse, t1)
     return y, None
+
+
+def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[torch.Tensor], dy: torch.Tensor,
+                        need_dx: bool, need_prompt: bool):
+    """Backward of ``swin_block_forward``: returns (dx | None, dprompt | None, dts | None).
+
+    ``dts`` is the gradient of the ``[heads, Np]`` prompt-token bias scores; autograd carries it into
+    ``pe.weights_token`` / ``pe.enc_token``.  When ``need_dx`` is False (first prompted block behind a frozen
+    stem) only the prompt key columns of the attention backward are computed."""
+    d, tb = sv.desc, sv.tb
+    if w.wqkv_t is None:
+        raise RuntimeError("swin_block_backward: weights were prepared without transposed copies")
+    dev = dy.device
+    st = L.stream()
+    Cc, heads = d.C, d.heads
+    hd = Cc // heads
+    BP = d.B * d.P
+    d_o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
+    d_t1 = torch.empty_like(d_o)
+    L.call("mivp_swin_proj_mlp_bwd", C.byref(d), L.ptr(dy), L.ptr(tb.tok_dst), L.ptr(sv.t1), L.ptr(w.ln2_w), L.ptr(w.ln2_b),
+           L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), st)
+    delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
+    L.call("mivp_win_attn_delta", C.byref(d), L.ptr(sv.o), L.ptr(d_o), L.ptr(delta), st)
+    dx = dprompt = dts = None
+    dk = dv = None
+    if need_dx:
+        dq = torch.empty_like(sv.q)
+        L.call("mivp_win_attn_bwd_dq", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
+               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dq), st)
+        dk = torch.empty_like(sv.k)
+        dv = torch.empty_like(sv.v)
+    has_prompt = d.Np > 0
+    dkp_part = dvp_part = dtok_part = None
+    if has_prompt and need_prompt:
+        dkp_part = torch.empty((BP * heads, d.Npp, hd), dtype=torch.float32, device=dev)
+        dvp_part = torch.empty_like(dkp_part)
+        dtok_part = torch.empty((BP * heads, d.Npp), dtype=torch.float32, device=dev)
+    if need_dx or (has_prompt and need_prompt):
+        if has_prompt and dkp_part is None:          # kernel always emits the prompt partials when prompts exist
+            dkp_part = torch.empty((BP * heads, d.Npp, hd), dtype=torch.float32, device=dev)
+            dvp_part = torch.empty_like(dkp_part)
+            dtok_part = torch.empty((BP * heads, d.Npp), dtype=torch.float32, device=dev)
+        L.call("mivp_win_attn_bwd_dkv", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
+               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dk), L.ptr(dv),
+               L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), st)
+    if need_dx:
+        dx = torch.empty_like(sv.x)
+        L.call("mivp_swin_qkv_bwd", C.byref(d), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(sv.x), L.ptr(tb.tok_src),
+               L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv_t), L.ptr(d_t1), L.ptr(dx), st)
+    if has_prompt and need_prompt:
+        rows = heads * d.Npp * hd
+        dkp = torch.empty((heads, d.Npp, hd), dtype=torch.float32, device=dev)
+        dvp = torch.empty_like(dkp)
+        dtok = torch.empty((heads, d.Npp), dtype=torch.float32, device=dev)
+        L.call("mivp_reduce_rows", L.ptr(dkp_part), C.c_int64(BP), C.c_int64(rows), L.ptr(dkp), st)
+        L.call("mivp_reduce_rows", L.ptr(dvp_part), C.c_int64(BP), C.c_int64(rows), L.ptr(dvp), st)
+        L.call("mivp_reduce_rows", L.ptr(dtok_part), C.c_int64(BP), C.c_int64(heads * d.Npp), L.ptr(dtok), st)
+        pr = prompt.detach().to(torch.float32).contiguous()
+        dprompt = torch.empty_like(pr)
+        L.call("mivp_prompt_kv_bwd", C.byref(d), L.ptr(dkp), L.ptr(dvp), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b),
+               L.ptr(w.wqkv), L.ptr(dprompt), st)
+        dts = dtok[:, :d.Np].contiguous()
+    return dx, dprompt, dts

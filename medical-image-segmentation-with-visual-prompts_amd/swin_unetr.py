@@ -1,0 +1,479 @@
+"""Drop-in ``SwinUnetR(conf)`` whose arithmetic runs in the HIP kernels of libmivp_hip.so.
+
+Surface kept from the reference (swin_unetr/swin_unetr.py:8-527): constructor taking the config
+Namespace (positionally or as ``conf=``), attributes ``input_layer / encoder_blocks / bottleneck /
+residual_blocks / decoder_blocks / output_layer / prompt_tokens / extra_heads / conf``, ``forward(x)
+-> dict`` with the reference's keys, the five ``named_parameters_*`` helpers, and a ``state_dict``
+with the reference's names, shapes, dtypes and ordering (checked against the
+reference's own key list in tests/test_module_surface.py).
+
+How it is built: the sub-modules are stock ``torch.nn`` layers used purely as *parameter holders*
+(same registration order as the reference => same keys and same default initialisation); none of
+their ``forward`` methods is ever called.  ``forward`` below walks channels-last bf16 activations
+through autograd Functions (functional.py) that launch the kernels.  There is no CPU path: a CPU
+tensor raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+TRAINING_MODES = (
+    "self_supervised_learning_encoder",
+    "self_supervised_learning_decoder",
+    "self_supervised_learning_all",
+    "supervised_learning_decoder",
+    "supervised_learning_all",
+    "downstream",
+)
+
+
+def _xavier(*shape):
+    return nn.Parameter(nn.init.xavier_uniform_(torch.empty(shape), gain=nn.init.calculate_gain("linear")))
+
+
+class RelativePE(nn.Module):
+    """Parameter holder of the separable relative-position bias
+    (multi_head_attention/relative_positional_encoding.py:7-154)."""
+
+    def __init__(self, embed_dim, num_heads, max_abs_pos, max_cap_dist, max_prompts, tokens_per_prompt,
+                 use_token_params=True):
+        super().__init__()
+        self.scale = embed_dim ** -0.5
+        self.num_heads = num_heads
+        self.enc_content_h = _xavier(2 * max_cap_dist[0] - 1, embed_dim)
+        self.enc_content_w = _xavier(2 * max_cap_dist[1] - 1, embed_dim)
+        self.enc_content_d = _xavier(2 * max_cap_dist[2] - 1, embed_dim)
+        for axis, name in enumerate("hwd"):
+            i = torch.arange(max_abs_pos[axis], dtype=torch.long)
+            dist = (i.view(1, -1) - i.view(-1, 1) + max_cap_dist[axis] - 1).clamp(0, 2 * (max_cap_dist[axis] - 1))
+            self.register_buffer(f"relative_dist_{name}", dist)
+        self.weights_content_h = _xavier(num_heads, embed_dim)
+        self.weights_content_w = _xavier(num_heads, embed_dim)
+        self.weights_content_d = _xavier(num_heads, embed_dim)
+        self.use_token_params = use_token_params
+        if use_token_params:
+            self.enc_token = nn.ParameterList([_xavier(tokens_per_prompt, embed_dim) for _ in range(max_prompts)])
+            self.weights_token = _xavier(num_heads, embed_dim)
+
+    def content_tables(self):
+        """Three per-axis tables ``[heads, 2w-1]`` (already times scale/3): entry j-i+w-1 is the bias
+        contribution of a key at slot coordinate j to a query at slot coordinate i."""
+        s = self.scale / 3.0
+        return tuple(((getattr(self, f"weights_content_{a}") @ getattr(self, f"enc_content_{a}").t()) * s).float().contiguous()
+                     for a in "hwd")
+
+    def token_scores(self, n_prompt):
+        """``[heads, n_prompt]`` bias of the prompt-token key columns (times scale)."""
+        emb = torch.cat(list(self.enc_token))[:n_prompt]
+        return ((self.weights_token @ emb.t()) * self.scale).float().contiguous()
+
+    def named_parameters_bias_content(self):
+        return [(n, p) for n, p in self.named_parameters() if "enc_content" in n or "weights_content" in n]
+
+    def named_parameters_bias_prompt_tokens(self):
+        return [(n, p) for n, p in self.named_parameters() if "enc_token" in n or "weights_token" in n]
+
+
+class WindowAttention(nn.Module):
+    """Parameter holder (multi_head_attention/window_attention.py:11-33)."""
+
+    def __init__(self, dim, num_heads, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if dim % num_heads != 0:
+            raise ValueError("WindowAttention: The dimension is not compatible with the number of heads!")
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(dim, dim, bias=False)
+        self.to_v = nn.Linear(dim, dim, bias=False)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class SwinTransformerBlock(nn.Module):
+    """One (shifted-)window attention block (swin_transformer/swin_block.py:98-289)."""
+
+    def __init__(self, hidden_channels, window_size, pos_bias_embed_dim, num_heads, max_prompts, tokens_per_prompt,
+                 use_token_params=True, shift_size=None, attn_drop=0.0, proj_drop=0.0, use_checkpoint=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.window_size = tuple(int(v) for v in window_size)
+        self.shift_size = tuple(int(v) for v in (shift_size or (0, 0, 0)))
+        self.use_checkpoint = use_checkpoint      # no-op: the fused kernels save O(tokens) state only
+        self.embed_dim = pos_bias_embed_dim
+        self.pe = RelativePE(pos_bias_embed_dim, num_heads, window_size, window_size, max_prompts, tokens_per_prompt,
+                             use_token_params)
+        self.attn_norm = nn.LayerNorm(hidden_channels, eps=1e-6)
+        self.attn = WindowAttention(hidden_channels, num_heads, attn_drop, proj_drop)
+        self.mlp_norm = nn.LayerNorm(hidden_channels, eps=1e-6)
+        self.mlp = nn.Linear(hidden_channels, hidden_channels)
+        self._wcache = Fn.WeightCache()
+
+    def forward(self, x, p=None):
+        """x: bf16 channels-last [B,H,W,D,C]; p: [Np, C] prompt parameter (or the reference's
+        batch-broadcast [B,Np,C], of which row 0 is used -- all rows are identical)."""
+        if self.training and (self.attn.attn_drop.p > 0 or self.attn.proj_drop.p > 0):
+            raise NotImplementedError("mivp_amd: dropout inside the fused Swin kernels is not built yet; "
+                                      "run with attn_drop = proj_drop = 0")
+        if p is not None and p.dim() == 3:
+            p = p[0]
+        return Fn.swin_block(self, x, p)
+
+    def named_parameters_body(self):
+        out = []
+        for m in (self.attn_norm, self.attn, self.mlp_norm, self.mlp):
+            out.extend(m.named_parameters())
+        return out
+
+    def named_parameters_bias_content(self):
+        return list(self.pe.named_parameters_bias_content())
+
+    def named_parameters_bias_prompt_tokens(self):
+        return list(self.pe.named_parameters_bias_prompt_tokens())
+
+
+class PatchMerging(nn.Module):
+    """2x2x2 / 2x2x1 merge (swin_transformer/down.py:6-60)."""
+
+    def __init__(self, in_channels, out_channels, merge_last_dim=True):
+        super().__init__()
+        k = 8 if merge_last_dim else 4
+        self.norm = nn.LayerNorm(k * in_channels, eps=1e-6)
+        self.reduction = nn.Linear(k * in_channels, out_channels, bias=False)
+        self.merge_last_dim = merge_last_dim
+        self._wcache = Fn.WeightCache()
+
+    def forward(self, x):
+        return Fn.patch_merge(self, x)
+
+    def named_parameters_body(self):
+        return [*self.reduction.named_parameters(), *self.norm.named_parameters()]
+
+
+class ConsecutiveSwinBlocks(nn.Module):
+    """W-MSA block, SW-MSA block, optional merge (swin_transformer/swin_block.py:16-95)."""
+
+    def __init__(self, hidden_channels, num_heads, pos_bias_embed_dim, max_prompts, tokens_per_prompt, window_size,
+                 use_token_params=True, shift_size=None, down=True, merge_last_dim=True, use_checkpoint=False,
+                 out_channels=None, proj_drop=0.0, attn_drop=0.0):
+        super().__init__()
+        self.window_size = tuple(int(v) for v in window_size)
+        self.shift_size = tuple(shift_size) if shift_size is not None else tuple(v // 2 for v in self.window_size)
+        self.down = down
+        self.swin_blocks = nn.ModuleList([
+            SwinTransformerBlock(hidden_channels, self.window_size, pos_bias_embed_dim, num_heads, max_prompts,
+                                 tokens_per_prompt, use_token_params, (0, 0, 0) if i == 0 else self.shift_size,
+                                 attn_drop, proj_drop, use_checkpoint)
+            for i in range(2)])
+        if down:
+            self.merge = PatchMerging(hidden_channels, out_channels or 2 * hidden_channels, merge_last_dim)
+
+    def forward(self, x, p=(None, None)):
+        for blk, prm in zip(self.swin_blocks, p):
+            x = blk(x, prm)
+        return self.merge(x) if self.down else x
+
+    def named_parameters_body(self):
+        out = []
+        for blk in self.swin_blocks:
+            out.extend(blk.named_parameters_body())
+        if self.down:
+            out.extend(self.merge.named_parameters())
+        return out
+
+    def named_parameters_bias_content(self):
+        return [q for blk in self.swin_blocks for q in blk.named_parameters_bias_content()]
+
+    def named_parameters_bias_prompt_tokens(self):
+        return [q for blk in self.swin_blocks for q in blk.named_parameters_bias_prompt_tokens()]
+
+
+class _ConvHolder(nn.Sequential):
+    """State-dict twin of MONAI ``Convolution(..., conv_only=True)``: one child named ``conv``."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("conv", nn.Conv3d(cin, cout, 3, 1, padding=1, bias=True))
+
+
+class SwinUpBlock(nn.Module):
+    """Decoder stage (swin_unetr/unet_blocks.py:11-92): upsample, crop+concat, BN, LeakyReLU, conv 3^3,
+    two Swin blocks."""
+
+    def __init__(self, in_channels, out_channels, strides, kernel_size, pos_bias_embed_dim, num_heads, window_size,
+                 max_prompts, tokens_per_prompt, use_token_params=True, act="leakyrelu", norm="batch", attn_drop=0.0,
+                 proj_drop=0.0, use_checkpoint=False, hidden_channels=None):
+        super().__init__()
+        self.strides = tuple(int(s) for s in strides)
+        self.up = nn.Upsample(scale_factor=tuple(float(s) for s in strides), mode="trilinear", align_corners=False)
+        self.act = nn.LeakyReLU()
+        hidden = hidden_channels if hidden_channels is not None else in_channels + in_channels // 2
+        self.norm_concat = nn.BatchNorm3d(hidden)
+        self.conv_concat = _ConvHolder(hidden, out_channels)
+        self.swin_layer = ConsecutiveSwinBlocks(out_channels, num_heads, pos_bias_embed_dim, max_prompts,
+                                                tokens_per_prompt, window_size, use_token_params, down=False,
+                                                attn_drop=attn_drop, proj_drop=proj_drop, use_checkpoint=use_checkpoint)
+        self._wcache = Fn.WeightCache()
+
+    def forward(self, x, c, p=(None, None)):
+        y = Fn.upcat(x, c, self.strides)
+        y = Fn.bn_act_conv(self, self.norm_concat, self.conv_concat.conv, y, lrelu=True)
+        return self.swin_layer(y, p)
+
+    def named_parameters_body(self):
+        return [*self.norm_concat.named_parameters(), *self.conv_concat.named_parameters(),
+                *self.swin_layer.named_parameters_body()]
+
+    def named_parameters_bias_content(self):
+        return self.swin_layer.named_parameters_bias_content()
+
+    def named_parameters_bias_prompt_tokens(self):
+        return self.swin_layer.named_parameters_bias_prompt_tokens()
+
+
+class SwinUnetR(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.input_layer = None
+        self.encoder_blocks = None
+        self.bottleneck = None
+        self.residual_blocks = None
+        self.decoder_blocks = None
+        self.output_layer = None
+        self.prompt_tokens = nn.ModuleDict()
+        self.extra_heads = nn.ModuleDict()
+        self.conf = conf
+        self._wcache = Fn.WeightCache()
+        mode = conf.training_mode
+        if mode not in TRAINING_MODES:
+            raise ValueError(f"Training mode {mode} not available!")
+        if mode == "self_supervised_learning_encoder":
+            self._build_encoder()
+            self._build_encoder_heads()
+            if conf.use_encoder_prompting:
+                self._build_prompts_enc()
+        else:
+            self._build_decoder()
+            if mode == "downstream":
+                self.extra_heads["downstream"] = nn.Sequential(
+                    nn.BatchNorm3d(conf.hidden_channels[0]),
+                    nn.Conv3d(conf.hidden_channels[0], conf.output_channels_downstream, 3, 1, padding=1))
+        # what is frozen in which mode (swin_unetr.py:21-44)
+        if mode in ("self_supervised_learning_decoder", "supervised_learning_decoder"):
+            for _, q in self.named_parameters_encoder(include_prompt_tokens=conf.use_encoder_prompting):
+                q.requires_grad = False
+        elif mode == "downstream":
+            for _, q in self.named_parameters_encoder(include_prompt_tokens=False):
+                q.requires_grad = False
+            for _, q in self.named_parameters_decoder(include_prompt_tokens=False):
+                q.requires_grad = False
+
+    # ------------------------------------------------------------------ construction
+    def _build_encoder(self):
+        c = self.conf
+        hc = list(c.hidden_channels)
+        self.input_layer = nn.Sequential(
+            nn.Conv3d(c.input_channels, hc[0], kernel_size=tuple(c.input_patch_size), stride=tuple(c.input_patch_size)),
+            nn.BatchNorm3d(hc[0], eps=1e-6))
+        self.encoder_blocks = nn.ModuleList([
+            ConsecutiveSwinBlocks(hc[i], c.num_heads_encoder * (2 ** i), c.pos_bias_embed_dim, c.max_prompts,
+                                  c.tokens_per_prompt_encoder, c.attn_window_size,
+                                  use_token_params=c.use_encoder_prompting, down=True, merge_last_dim=(i < 1),
+                                  use_checkpoint=c.use_checkpoint, proj_drop=c.proj_drop, attn_drop=c.attn_drop)
+            for i in range(c.depth_unet)])
+
+    def _build_encoder_heads(self):
+        c = self.conf
+        hc = list(c.hidden_channels)
+        depth = c.depth_unet
+        if c.use_reconstruction or c.use_mutual_learning:
+            chs = [hc[-1] // (2 ** i) for i in range(depth + 1)] + [hc[-1] // (2 ** depth)]
+            layers: List[nn.Module] = []
+            for i in range(depth + 1):
+                layers += [nn.Conv3d(chs[i], chs[i + 1], 3, 1, 1), nn.InstanceNorm3d(chs[i + 1]), nn.LeakyReLU(),
+                           nn.Upsample(scale_factor=(2, 2, 1 if i < depth - 1 else 2), mode="trilinear", align_corners=True)]
+            layers.append(nn.Conv3d(chs[-1], c.input_channels, 1, 1))
+            self.extra_heads["reconstruction"] = nn.Sequential(*layers)
+        if c.use_rotation_prediction:
+            self.extra_heads["rotation_prediction"] = nn.Linear(hc[-1], 4)
+        if c.use_contrastive_learning:
+            self.extra_heads["contrastive_coding"] = nn.Linear(hc[-1], c.contrastive_coding_dim)
+
+    def _build_decoder(self):
+        c = self.conf
+        hc = list(c.hidden_channels)
+        depth = c.depth_unet
+        if c.unetr_up_block != "swin" or c.unetr_res_block == "full":
+            raise NotImplementedError(
+                "mivp_amd: the MONAI UnetrUpBlock / UnetrBasicBlock options are not built (the UnetrUpBlock path "
+                "is not runnable in the reference either, SURVEY 8 a16); use unetr_up_block='swin' and "
+                "unetr_res_block in ('none', 'simple')")
+        self._build_encoder()
+        dec_in = [hc[i + 1] for i in range(depth)][::-1]       # channels entering each decoder stage
+        dec_out = [hc[i] for i in range(depth)][::-1]
+        self.bottleneck = nn.Conv3d(dec_in[0], dec_in[0], 3, 1, padding=1)
+        if c.unetr_res_block == "simple":
+            self.residual_blocks = nn.ModuleList(
+                [nn.Conv3d(dec_out[i], dec_out[i], 3, 1, padding=1) for i in range(depth)]
+                + [nn.Conv3d(c.input_channels, dec_out[-1], 3, 1, padding=1)])
+        else:
+            self.residual_blocks = nn.ModuleList([nn.Identity() for _ in range(depth + 1)])
+        self.decoder_blocks = nn.ModuleList([
+            SwinUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), (3, 3, 3), c.pos_bias_embed_dim,
+                        c.num_heads_decoder, c.attn_window_size, c.max_prompts, c.tokens_per_prompt_decoder,
+                        use_token_params=c.use_decoder_prompting, attn_drop=c.attn_drop, proj_drop=c.proj_drop,
+                        use_checkpoint=c.use_checkpoint)
+            for i in range(depth)])
+        if c.unetr_res_block == "none":
+            self.output_layer = nn.Upsample(scale_factor=(2, 2, 2), mode="trilinear", align_corners=False)
+        else:
+            self.output_layer = SwinUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), (3, 3, 3), c.pos_bias_embed_dim,
+                                            c.num_heads_decoder, c.attn_window_size, c.max_prompts,
+                                            c.tokens_per_prompt_decoder, attn_drop=c.attn_drop, proj_drop=c.proj_drop,
+                                            use_checkpoint=c.use_checkpoint, hidden_channels=2 * dec_out[-1])
+        if c.training_mode in ("supervised_learning_decoder", "supervised_learning_all"):
+            self.extra_heads["segmentation"] = nn.Sequential(
+                nn.BatchNorm3d(hc[0]), nn.Conv3d(hc[0], c.output_channels_pretrain, 3, 1, padding=1))
+        if c.use_encoder_prompting:
+            self._build_prompts_enc()
+        if c.use_decoder_prompting:
+            self._build_prompts_dec()
+
+    def _build_prompts_enc(self):
+        c = self.conf
+        self.prompt_tokens["enc"] = nn.ParameterList(
+            [_xavier(c.tokens_per_prompt_encoder, c.hidden_channels[i // 2]) for i in range(2 * c.depth_unet)])
+
+    def _build_prompts_dec(self):
+        c = self.conf
+        hc = c.hidden_channels
+        self.prompt_tokens["dec"] = nn.ParameterList(
+            [_xavier(c.tokens_per_prompt_decoder, hc[-(i + 1) // 2 - 1]) for i in range(2 * c.depth_unet)])
+        if c.unetr_res_block != "none" and c.unetr_up_block == "swin":
+            self.prompt_tokens["out"] = nn.ParameterList(
+                [_xavier(c.tokens_per_prompt_decoder, hc[0]) for _ in range(2)])
+
+    # ------------------------------------------------------------------ forward
+    def _prompts(self, side, j):
+        if side == "enc" and not self.conf.use_encoder_prompting:
+            return (None, None)
+        if side in ("dec", "out") and not self.conf.use_decoder_prompting:
+            return (None, None)
+        lst = self.prompt_tokens[side]
+        return (lst[2 * j], lst[2 * j + 1])
+
+    def forward_swin_transformer(self, x):
+        """Returns channels-last bf16 features, deepest first, input volume last (as the reference's
+        ``out_vit`` list, swin_unetr.py:46-63)."""
+        feats = [x]
+        enc = Fn.patch_embed(self, self.input_layer[0], self.input_layer[1], x)
+        feats.insert(0, enc)
+        for j in range(self.conf.depth_unet):
+            enc = self.encoder_blocks[j](enc, self._prompts("enc", j))
+            feats.insert(0, enc)
+        return feats
+
+    def forward_decoder(self, feats):
+        c = self.conf
+        depth = c.depth_unet
+        dec = Fn.conv3d_plain(self, "bottleneck", self.bottleneck, feats[0], residual=feats[0])
+        for j in range(depth):
+            skip = feats[j + 1]
+            if c.unetr_res_block == "simple":
+                skip = Fn.conv3d_plain(self, f"res{j}", self.residual_blocks[j], skip)
+            dec = self.decoder_blocks[j](dec, skip, self._prompts("dec", j))
+        if c.unetr_res_block == "none":
+            return Fn.upcat(dec, None, (2, 2, 2))
+        skip = Fn.conv3d_plain(self, f"res{depth}", self.residual_blocks[depth], Fn.to_channels_last(feats[-1]))
+        return self.output_layer(dec, skip, self._prompts("out", 0))
+
+    def forward(self, x):
+        """x: float [B, Cin, H, W, D] on the GPU -> dict as the reference (swin_unetr.py:129-144);
+        volumes in the dict are channels-first *views* of channels-last storage."""
+        Fn.require_device(x)
+        mode = self.conf.training_mode
+        feats = self.forward_swin_transformer(x)
+        if mode == "self_supervised_learning_encoder":
+            return self._encoder_outputs(feats)
+        latent = self.forward_decoder(feats)
+        if mode == "downstream":
+            seg = Fn.bn_act_conv(self, self.extra_heads["downstream"][0], self.extra_heads["downstream"][1], latent,
+                                 lrelu=False, out_f32=True, key="head_downstream")
+            return {"downstream": Fn.to_channels_first(seg)}
+        out = {"latent_outputs": Fn.to_channels_first(latent)}
+        if mode in ("supervised_learning_decoder", "supervised_learning_all"):
+            seg = Fn.bn_act_conv(self, self.extra_heads["segmentation"][0], self.extra_heads["segmentation"][1], latent,
+                                 lrelu=False, out_f32=True, key="head_segmentation")
+            out["seg_pred"] = Fn.to_channels_first(seg)
+        return out
+
+    def _encoder_outputs(self, feats):
+        c = self.conf
+        out = {}
+        if any(k in self.extra_heads for k in ("reconstruction", "rotation_prediction", "contrastive_coding")):
+            raise NotImplementedError(
+                "mivp_amd: the phase-1 proxy-task heads (reconstruction / rotation / contrastive, swin_unetr.py:185-222) "
+                "are outside the hot path built so far; construct the model with those flags off")
+        out["out_vit"] = [Fn.to_channels_first(f) if f.dim() == 5 and f.dtype == torch.bfloat16 else f for f in feats]
+        return out
+
+    # ------------------------------------------------------------------ parameter groups (swin_unetr.py:433-527)
+    def named_parameters_downstream(self):
+        out = []
+        if self.conf.use_encoder_prompting:
+            out.extend(self.named_parameters_prompt_tokens_encoder())
+        if self.conf.use_decoder_prompting:
+            out.extend(self.named_parameters_prompt_tokens_decoder())
+        out.extend(self.extra_heads["downstream"].named_parameters())
+        return out
+
+    def named_parameters_prompt_tokens_encoder(self):
+        out = list(self.prompt_tokens["enc"].named_parameters())
+        for blk in self.encoder_blocks:
+            out.extend(blk.named_parameters_bias_prompt_tokens())
+        return out
+
+    def named_parameters_prompt_tokens_decoder(self):
+        tokens = list(self.prompt_tokens["dec"].named_parameters())
+        bias = []
+        for blk in self.decoder_blocks:
+            bias.extend(blk.named_parameters_bias_prompt_tokens())
+        if self.conf.unetr_res_block != "none" and self.conf.unetr_up_block == "swin":
+            tokens.extend(self.prompt_tokens["out"].named_parameters())
+        if self.conf.unetr_res_block != "none":
+            bias.extend(self.output_layer.named_parameters_bias_prompt_tokens())
+        return tokens + bias
+
+    def named_parameters_encoder(self, include_prompt_tokens=False):
+        out = list(self.input_layer.named_parameters())
+        for blk in self.encoder_blocks:
+            out.extend(blk.named_parameters_body())
+            out.extend(blk.named_parameters_bias_content())
+        if include_prompt_tokens and self.conf.use_encoder_prompting:
+            out.extend(self.named_parameters_prompt_tokens_encoder())
+        if self.conf.training_mode == "self_supervised_learning_encoder":
+            for head in self.extra_heads.values():
+                out.extend(head.named_parameters())
+        return out
+
+    def named_parameters_decoder(self, include_prompt_tokens=False):
+        out = list(self.bottleneck.named_parameters())
+        for blk in self.residual_blocks:
+            out.extend(blk.named_parameters())
+        for blk in self.decoder_blocks:
+            out.extend(blk.named_parameters_body())
+            out.extend(blk.named_parameters_bias_content())
+        if self.conf.unetr_res_block != "none":
+            out.extend(self.output_layer.named_parameters_body())
+            out.extend(self.output_layer.named_parameters_bias_content())
+        if include_prompt_tokens and self.conf.use_decoder_prompting:
+            out.extend(self.named_parameters_prompt_tokens_decoder())
+        if self.conf.training_mode in ("supervised_learning_decoder", "supervised_learning_all"):
+            out.extend(self.extra_heads["segmentation"].named_parameters())
+        return out

@@ -60,7 +60,7 @@ def test_block_forward_golden_shapes(tag):
     dev = torch.device("cuda")
     w = swin_ops.weights_from_state(sd, "", m["heads"], 64, m["n_prompt"], dev)
     xc = x.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
-    y, _ = swin_ops.swin_block_forward(xc, None if prm is None else prm.to(dev), w, m["window"], m["shift"])
+    y, _ = swin_ops.swin_block_forward(xc, None if prm is None else prm.to(dev), w, None, m["window"], m["shift"])
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
     err = rel_l2(got, want)
@@ -97,7 +97,7 @@ def test_block_forward_real_sizes(window, dims, C, heads, n_prompt, shift):
     dev = torch.device("cuda")
     w = swin_ops.weights_from_state(sd, "", heads, 64, n_prompt, dev)
     xc = x.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
-    y, _ = swin_ops.swin_block_forward(xc, None if prm is None else prm.to(dev), w, window, shift)
+    y, _ = swin_ops.swin_block_forward(xc, None if prm is None else prm.to(dev), w, None, window, shift)
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
     err = rel_l2(got, want)

@@ -1,0 +1,149 @@
+"""GPU parity of the Swin-block and patch-merge BACKWARD kernels against autograd over the oracle.
+
+Gradients flow through several bf16 rounding points (dO, dt1, dq/dk/dv, dS, dx), so the tolerance is
+looser than forward: rel-L2 <= 1.5e-2 for dx (bf16 tensor), <= 1.5e-2 for the fp32 prompt / prompt-bias
+gradients (they are sums over every window of bf16-rounded products)."""
+import pytest
+import torch
+
+from conftest import load_fixture, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _rounded_state(sd):
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() == 2 and ("to_" in k or "proj.weight" in k or k.endswith("mlp.weight")
+                                                       or "reduction" in k):
+            out[k] = r16(v)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def _run_block(sd, x, prm, gout, window, shift, heads, need_dx=True):
+    import mivp_amd
+    from mivp_amd import swin_ops
+    from oracle import swin_ref as S
+    n_prompt = 0 if prm is None else prm.shape[0]
+    sdo = {k: v.clone() for k, v in sd.items()}
+    tok_keys = [k for k in sdo if "weights_token" in k or "enc_token" in k] if n_prompt else []
+    for k in tok_keys:
+        sdo[k].requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    po = prm.clone().requires_grad_(True) if prm is not None else None
+    want = S.swin_block(xo, po, sdo, "", window, shift, heads)
+    want.backward(gout)
+    w = swin_ops.weights_from_state(sd, "", heads, 64, 0, torch.device(DEV), need_bwd=True)
+    ts = None
+    leafs = {}
+    if n_prompt:
+        for k in tok_keys:
+            leafs[k] = sd[k].clone().to(DEV).requires_grad_(True)
+        ts = (leafs["pe.weights_token"] @ leafs["pe.enc_token.0"].t())[:, :n_prompt] * (64 ** -0.5)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = None if prm is None else prm.to(DEV)
+    y, saved = swin_ops.swin_block_forward(xc, pd, w, ts, window, shift, save=True)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dx, dprompt, dts = swin_ops.swin_block_backward(saved, w, pd, dy, need_dx, n_prompt > 0)
+    torch.cuda.synchronize()
+    res = {"y": (rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), want), None)}
+    if need_dx:
+        res["dx"] = (rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), xo.grad), None)
+    if n_prompt:
+        res["dprompt"] = (rel_l2(dprompt.cpu(), po.grad), None)
+        ts.backward(dts)
+        for k in tok_keys:
+            res["d" + k] = (rel_l2(leafs[k].grad.cpu(), sdo[k].grad), None)
+    return res
+
+
+BLOCKS = ["nopad_noshift", "nopad_shift", "nopad_shift_prompt", "oddpad_shift_prompt",
+          "evenpad_noshift_prompt", "smalldim_shift", "smalldim_pad_prompt", "w442_shift_prompt"]
+
+
+@pytest.mark.parametrize("tag", BLOCKS)
+def test_block_backward_golden_shapes(tag):
+    fx = load_fixture(f"block_{tag}")
+    m = fx.meta
+    sd = _rounded_state(fx["sd"])
+    res = _run_block(sd, r16(fx["in"]["x"]), fx["in"].get("prompt"), r16(fx["in"]["gout"]), m["window"], m["shift"],
+                     m["heads"])
+    assert res["y"][0] < 6e-3
+    for k, (err, _) in res.items():
+        assert err < 1.5e-2, (tag, k, err)
+
+
+@pytest.mark.parametrize("window,dims,C,heads,n_prompt,shift,need_dx", [
+    ((7, 7, 7), (14, 14, 14), 48, 4, 64, (3, 3, 3), True),
+    ((7, 7, 7), (14, 14, 14), 48, 4, 64, (0, 0, 0), False),   # first prompted block: prompt gradients only
+    ((7, 7, 7), (12, 12, 24), 96, 8, 64, (3, 3, 3), True),
+    ((7, 7, 7), (6, 6, 24), 192, 16, 64, (3, 3, 3), True),
+    ((7, 7, 7), (12, 12, 24), 96, 4, 0, (3, 3, 3), True),       # decoder, hd 24, no prompts
+    ((7, 7, 7), (6, 6, 24), 192, 4, 64, (3, 3, 3), True),       # decoder with prompts, hd 48 (chunked LDS)
+    ((8, 8, 4), (16, 16, 8), 48, 4, 64, (4, 4, 2), True),
+])
+def test_block_backward_real_sizes(window, dims, C, heads, n_prompt, shift, need_dx):
+    from oracle.unetr_ref import _block_state
+    gen = torch.Generator().manual_seed(2)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, max(n_prompt, 1), n_prompt > 0, gen)
+    for k in list(sd):
+        if "norm.weight" in k:
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=gen)
+        if "norm.bias" in k or k.endswith("proj.bias") or k.endswith("mlp.bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=gen)
+    sd = _rounded_state(sd)
+    x = r16(torch.randn(1, C, *dims, generator=gen))
+    prm = 0.5 * torch.randn(n_prompt, C, generator=gen) if n_prompt else None
+    gout = r16(torch.randn(1, C, *dims, generator=gen))
+    res = _run_block(sd, x, prm, gout, window, shift, heads, need_dx)
+    for k, (err, _) in res.items():
+        assert err < 1.5e-2, (k, err)
+
+
+@pytest.mark.parametrize("tag", ["even_T", "odd_T", "even_F", "odd_F"])
+def test_patch_merge_backward_golden(tag):
+    import mivp_amd
+    from mivp_amd import ops
+    from oracle import swin_ref as S
+    fx = load_fixture(f"merge_{tag}")
+    sd = _rounded_state(fx["sd"])
+    x = r16(fx["in"]["x"]).requires_grad_(True)
+    want = S.patch_merge(x, sd, "", fx.meta["merge_last_dim"])
+    g = r16(fx["in"]["gout"])
+    want.backward(g)
+    xc = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy = g.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    w = sd["reduction.weight"]
+    dx = ops.patch_merge_backward(dy, xc, sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV),
+                                  w.t().contiguous().to(DEV, torch.bfloat16), fx.meta["merge_last_dim"])
+    torch.cuda.synchronize()
+    assert rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), x.grad) < 1e-2
+
+
+@pytest.mark.parametrize("C,dims,last", [(48, (8, 8, 8), True), (192, (4, 6, 5), False)])
+def test_patch_merge_backward_real_channels(C, dims, last):
+    import mivp_amd
+    from mivp_amd import ops
+    from oracle import swin_ref as S
+    g = torch.Generator().manual_seed(C)
+    k = 8 if last else 4
+    sd = {"norm.weight": 1 + 0.2 * torch.randn(k * C, generator=g), "norm.bias": 0.1 * torch.randn(k * C, generator=g),
+          "reduction.weight": r16(torch.randn(2 * C, k * C, generator=g) / (k * C) ** 0.5)}
+    x = r16(torch.randn(2, C, *dims, generator=g)).requires_grad_(True)
+    want = S.patch_merge(x, sd, "", last)
+    gout = r16(torch.randn(want.shape, generator=g))
+    want.backward(gout)
+    xc = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dx = ops.patch_merge_backward(dy, xc, sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV),
+                                  sd["reduction.weight"].t().contiguous().to(DEV, torch.bfloat16), last)
+    torch.cuda.synchronize()
+    assert rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), x.grad) < 1e-2
