@@ -81,3 +81,47 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f"mivp_amd: {name} failed with code {rc}: {lib().mivp_last_error().decode()}")
+
+
+# ---------------------------------------------------------------------------------------------
+# optional per-kernel timing (bench.py): HIP events on the stream the kernel is launched on
+# ---------------------------------------------------------------------------------------------
+_prof = {"name": None, "pred": None, "on": False, "events": [], "desc": None}
+
+
+def profile_select(name, pred=None):
+    """Time every call of C-ABI entry ``name`` whose ctypes args satisfy ``pred`` while profiling is on."""
+    _prof.update(name=name, pred=pred, events=[], desc=None)
+
+
+def profile_reset(on: bool):
+    if on:
+        _prof["events"] = []
+    _prof["on"] = on
+
+
+def profile_result():
+    """(mean launch duration in ms, launches, descriptor of the last timed launch)."""
+    ev = _prof["events"]
+    if not ev:
+        return 0.0, 0, None
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    return sum(ms) / len(ms), len(ms), _prof["desc"]
+
+
+_plain_call = call
+
+
+def call(name, *args):  # noqa: F811  (wraps the plain call with the optional event pair)
+    if _prof["on"] and name == _prof["name"] and (_prof["pred"] is None or _prof["pred"](args)):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        _plain_call(name, *args)
+        b.record()
+        _prof["events"].append((a, b))
+        d = args[0]._obj
+        _prof["desc"] = type(d).from_buffer_copy(d)
+        return
+    _plain_call(name, *args)

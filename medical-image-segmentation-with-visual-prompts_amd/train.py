@@ -1,0 +1,109 @@
+"""Training-step harness for the HIP SwinUnetR: the step body of the reference's
+``SegmentationTrainer.train`` (modules/segmentation.py:96-122) on synthetic data, single GPU or one
+process per GPU under ``torch.distributed`` (RCCL).
+
+The loss and optimizer are the "next" rows of SURVEY 8f (N1/N2): they run as stock PyTorch GPU ops
+for now (DiceFocal restated from MONAI's documented formulas -- parity unpinned, see
+oracle/loss_ref.py; ``torch.optim.AdamW(fused=True)``).
+"""
+from __future__ import annotations
+
+import os
+from argparse import Namespace
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the headline metric is quoted on
+    "cfg1": dict(training_mode="downstream", use_encoder_prompting=False, use_decoder_prompting=False,
+                 input_channels=1, size=96, batch=4),
+    # configs[2] (per-GPU shape): + encoder prompting
+    "cfg2": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=False,
+                 input_channels=1, size=96, batch=4),
+    # configs[3] (per-GPU shape): both prompt sides, 4-channel 128^3
+    "cfg3": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=True,
+                 input_channels=4, size=128, batch=1),
+    # smoke-sized
+    "tiny": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=True,
+                 input_channels=1, size=32, batch=2),
+}
+
+
+def make_conf(workload: str, window=(7, 7, 7)) -> Tuple[Namespace, int, int]:
+    """yml defaults of configurations/example_configs.yml with dropout off (the fused kernels have no
+    dropout yet) and the north star's 7x7x7 window; returns (conf, volume size, per-GPU batch)."""
+    w = dict(WORKLOADS[workload])
+    size, batch = w.pop("size"), w.pop("batch")
+    conf = Namespace(
+        depth_unet=3, hidden_channels=[48, 96, 192, 384], input_patch_size=[2, 2, 2], unetr_res_block="none",
+        unetr_up_block="swin", basic_block_res=True, num_heads_encoder=4, num_heads_decoder=4,
+        attn_window_size=list(window), pos_bias_embed_dim=64, use_checkpoint=False, attn_drop=0.0, proj_drop=0.0,
+        max_prompts=1, tokens_per_prompt_encoder=64, tokens_per_prompt_decoder=64,
+        use_reconstruction=False, use_mutual_learning=False, use_rotation_prediction=False,
+        use_contrastive_learning=False, contrastive_coding_dim=512, output_channels_downstream=2,
+        output_channels_pretrain=5, include_background=True, lr_downstream=1e-3, weight_decay_downstream=0.0, **w)
+    return conf, size, batch
+
+
+def synthetic_batch(conf: Namespace, batch: int, size: int, device, rank: int = 0):
+    """Images uniform in [0,1) like the reference's ScaleIntensityRanged output (datasets/transforms.py:41-44),
+    integer masks in [0, out_ch) stored as float like its label volumes (modules/utils.py:372-388)."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand(batch, conf.input_channels, size, size, size, generator=g)
+    y = torch.randint(0, conf.output_channels_downstream, (batch, 1, size, size, size), generator=g).float()
+    return x.to(device), y.to(device)
+
+
+def dice_focal_loss(logits: torch.Tensor, target: torch.Tensor, include_background: bool = True,
+                    gamma: float = 4.0) -> torch.Tensor:
+    """MONAI ``DiceFocalLoss(include_background, to_onehot_y=True, softmax=True, gamma=4)`` as documented
+    (segmentation.py:44-50): Dice on softmax probabilities (smooth 1e-5) + sigmoid focal loss, both
+    averaged.  logits [B,C,H,W,D] float, target [B,1,H,W,D] float class indices."""
+    C = logits.shape[1]
+    onehot = F.one_hot(target[:, 0].long(), C).permute(0, 4, 1, 2, 3).to(logits.dtype)
+    prob = logits.softmax(dim=1)
+    x = logits
+    if not include_background:
+        onehot, prob, x = onehot[:, 1:], prob[:, 1:], logits[:, 1:]
+    dims = (2, 3, 4)
+    inter = (prob * onehot).sum(dims)
+    denom = prob.sum(dims) + onehot.sum(dims)
+    dice = (1.0 - (2.0 * inter + 1e-5) / (denom + 1e-5)).mean()
+    bce = x - x * onehot - F.logsigmoid(x)
+    inv = F.logsigmoid(-x * (onehot * 2 - 1))
+    focal = ((inv * gamma).exp() * bce).mean()
+    return dice + focal
+
+
+def build_optimizer(model, conf: Namespace):
+    """AdamW over ``named_parameters_downstream()`` (segmentation.py:25-39)."""
+    core = model.module if hasattr(model, "module") else model
+    params = [p for _, p in core.named_parameters_downstream()]
+    return torch.optim.AdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream),
+                             fused=True)
+
+
+def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
+    out = model(x)
+    loss = dice_focal_loss(out["downstream"], y, conf.include_background, 4.0)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return loss.detach()
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local, world
+
+
+def wrap_ddp(model, local_rank: int):
+    """One process per GPU, gradient all-reduce over RCCL overlapped with backward (DDP buckets).
+    BatchNorm statistics stay per replica as in the (single-device) reference: no buffer broadcast."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    return DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
+               gradient_as_bucket_view=True)
