@@ -52,8 +52,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
         _lib = C.CDLL(LIB_PATH)
         _lib.mivp_last_error.restype = C.c_char_p
-        if hasattr(_lib, "mivp_conv3d_wgrad_small_ws"):
-            _lib.mivp_conv3d_wgrad_small_ws.restype = C.c_size_t
+        _lib.mivp_conv3d_wgrad_small_ws.restype = C.c_size_t
+        _lib.mivp_conv3d_wgrad_rows_ws.restype = C.c_size_t
         ver = _lib.mivp_abi_version()
         if ver != ABI_VERSION:
             raise RuntimeError(f"mivp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")

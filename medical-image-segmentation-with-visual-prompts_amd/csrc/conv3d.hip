@@ -319,3 +319,157 @@ extern "C" int mivp_conv3d_wgrad_small(const MivpConvDesc* d, const void* x, con
     if (rc) return rc;
     return mivp_reduce_rows(part, nb, (long)d->Cout * 27 * d->Cin + d->Cout, dwdb, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// small-Cout weight gradient on MFMA ("rows" formulation).
+//   G[(co,tap)][c] = sum_u dy[u - tap][co] * x[u][c]         (u over all voxels, dy zero outside)
+//   column Cin of G accumulates S[(co,tap)] = sum_{u in bounds} dy[u - tap][co]  (x extended by a 1)
+// A wave owns one (b,h,w) row of D voxels at a time: the row of x is staged TRANSPOSED in LDS
+// (xT[c][d]) and the nine neighbouring dy rows are staged transposed and pre-shifted along d
+// (DT[(co,tap)][d]), so both MFMA operands are 16-byte aligned K-major reads (K = voxels).
+// G and S are linear in the raw x: the BatchNorm affine in front of the conv, the conv weight
+// gradient, dgamma and dbeta all follow from (G, S) by O(27*Cout*Cin) algebra on the host.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NTC>
+__global__ __launch_bounds__(256) void k_conv3d_wgrad_rows(MivpConvDesc d, const bf16_t* __restrict__ x,
+                                                           const bf16_t* __restrict__ dy, int dy_stride,
+                                                           float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin, Cout = d.Cout;
+    const int Dp = (D + 31) / 32 * 32;
+    const int ROW = (Dp + 8) * 2;
+    char* xT = smem + (size_t)wave * (16 * (MT + NTC)) * ROW;
+    char* DT = xT + (size_t)(16 * NTC) * ROW;
+    const long rows_total = (long)d.B * H * W;
+    const long waves_total = (long)gridDim.x * 4;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long trips = (rows_total + waves_total - 1) / waves_total;
+    const int G8 = Cin / 8;
+
+    f32x4 acc[MT][NTC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = fzero4();
+
+    for (long it = 0; it < trips; ++it) {
+        const long row = wid + it * waves_total;
+        const bool live = row < rows_total;
+        __syncthreads();                                   // previous trip's reads are done
+        if (live) {
+            const long b = row / ((long)H * W);
+            const int h = (int)((row / W) % H), w = (int)(row % W);
+            // zero both images (pad columns, missing neighbours, shifted-out ends)
+            for (int e = lane; e < (16 * (MT + NTC)) * ROW / 16; e += 64) *reinterpret_cast<bf16x8*>(xT + 16 * e) = zero8();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // x row, transposed; extra channel Cin = 1 for in-bounds voxels
+            const bf16_t* xrow = x + ((b * H + h) * (long)W + w) * D * Cin;
+            for (int e = lane; e < D * G8; e += 64) {
+                const int dd = e / G8, cg = e - dd * G8;
+                const bf16x8 v = ld8(xrow + (long)dd * Cin + cg * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(xT + (size_t)(cg * 8 + j) * ROW + 2 * dd) = v[j];
+            }
+            for (int dd = lane; dd < D; dd += 64) *reinterpret_cast<bf16_t*>(xT + (size_t)Cin * ROW + 2 * dd) = (bf16_t)1.0f;
+            // nine neighbouring dy rows, transposed and shifted:  DT[co*27 + tap][dz + sd] = dy[(h-sh, w-sw, dz)][co]
+            for (int nb = 0; nb < 9; ++nb) {
+                const int sh = nb / 3 - 1, sw = nb % 3 - 1;
+                const int hh = h - sh, ww = w - sw;
+                if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                const bf16_t* drow = dy + ((b * H + hh) * (long)W + ww) * D * dy_stride;
+                for (int dz = lane; dz < D; dz += 64) {
+                    bf16_t vals[8];
+                    if (dy_stride == 8) { const bf16x8 v = ld8(drow + (long)dz * 8); for (int j = 0; j < 8; ++j) vals[j] = v[j]; }
+                    else { for (int j = 0; j < 8; ++j) vals[j] = j < Cout ? drow[(long)dz * dy_stride + j] : (bf16_t)0.0f; }
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) {
+                        if (co < Cout) {
+#pragma unroll
+                            for (int sd = -1; sd <= 1; ++sd) {
+                                const int dt = dz + sd;
+                                if (dt >= 0 && dt < D) {
+                                    const int tap = (nb / 3) * 9 + (nb % 3) * 3 + (sd + 1);
+                                    *reinterpret_cast<bf16_t*>(DT + (size_t)(co * 27 + tap) * ROW + 2 * dt) = vals[co];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int ks = 0; ks < Dp / 32; ++ks) {
+                bf16x8 bfr[NTC];
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) bfr[nt] = *reinterpret_cast<const bf16x8*>(xT + (size_t)(16 * nt + r) * ROW + (32 * ks + 8 * g) * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(DT + (size_t)(16 * mt + r) * ROW + (32 * ks + 8 * g) * 2);
+#pragma unroll
+                    for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = mfma16(a, bfr[nt], acc[mt][nt]);
+                }
+            }
+        }
+    }
+    // partial [wave][16*MT][16*NTC]
+    float* my = part + wid * (long)(16 * MT) * (16 * NTC);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) my[(long)(16 * mt + 4 * g + j) * (16 * NTC) + 16 * nt + r] = acc[mt][nt][j];
+}
+
+static int wgrad_rows_cfg(const MivpConvDesc* d, int* mt, int* ntc) {
+    const int rows = 27 * d->Cout, cols = d->Cin + 1;
+    *mt = rows <= 64 ? 4 : (rows <= 144 ? 9 : 0);
+    *ntc = cols <= 16 ? 1 : (cols <= 32 ? 2 : (cols <= 64 ? 4 : 0));
+    return (*mt && *ntc) ? MIVP_OK : MIVP_EUNSUPPORTED;
+}
+
+static int wgrad_rows_grid(const MivpConvDesc* d) {
+    const long rows = (long)d->B * d->dims[0] * d->dims[1];
+    long wg = (rows + 3) / 4;
+    if (wg > 512) wg = 512;
+    return (int)(wg < 1 ? 1 : wg);
+}
+
+extern "C" size_t mivp_conv3d_wgrad_rows_ws(const MivpConvDesc* d) {
+    int mt, ntc;
+    if (!d || wgrad_rows_cfg(d, &mt, &ntc)) return 0;
+    return (size_t)wgrad_rows_grid(d) * 4 * (16 * mt) * (16 * ntc);
+}
+
+extern "C" int mivp_conv3d_wgrad_rows(const MivpConvDesc* d, const void* x, const void* dy, int32_t dy_stride,
+                                      float* part, float* gs, mivp_stream_t stream) {
+    int rc = conv_checks(d);
+    if (rc) return rc;
+    MIVP_REQUIRE(x && dy && part && gs && dy_stride >= d->Cout && d->Cout <= 8);
+    int mt, ntc;
+    if (wgrad_rows_cfg(d, &mt, &ntc)) { mivp_set_error("conv3d_wgrad_rows: needs 27*Cout <= 144 and Cin < 64"); return MIVP_EUNSUPPORTED; }
+    const int dp = (d->dims[2] + 31) / 32 * 32;
+    const size_t lds = (size_t)4 * 16 * (mt + ntc) * (dp + 8) * 2;
+    if (lds > 160 * 1024) { mivp_set_error("conv3d_wgrad_rows: D too long for the LDS row images"); return MIVP_EUNSUPPORTED; }
+    const int grid = wgrad_rows_grid(d);
+    hipStream_t st = (hipStream_t)stream;
+#define WGR(M, N)                                                                                                   \
+    do {                                                                                                            \
+        auto kern = k_conv3d_wgrad_rows<M, N>;                                                                      \
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *d, (const bf16_t*)x, (const bf16_t*)dy, (int)dy_stride, part); \
+    } while (0)
+    if (mt == 4 && ntc == 1) WGR(4, 1);
+    else if (mt == 4 && ntc == 2) WGR(4, 2);
+    else if (mt == 4 && ntc == 4) WGR(4, 4);
+    else if (mt == 9 && ntc == 1) WGR(9, 1);
+    else if (mt == 9 && ntc == 2) WGR(9, 2);
+    else WGR(9, 4);
+#undef WGR
+    rc = mivp_check_launch("conv3d_wgrad_rows");
+    if (rc) return rc;
+    return mivp_reduce_rows(part, (int64_t)grid * 4, (int64_t)(16 * mt) * (16 * ntc), gs, stream);
+}

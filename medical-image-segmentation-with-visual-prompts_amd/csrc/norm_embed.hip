@@ -126,14 +126,17 @@ extern "C" int mivp_bn_stats(const void* x, int64_t n_vox, int32_t C, int32_t nb
 }
 
 // part [nblk][2C] -> batch mean / biased var -> scale, shift ; running stats (unbiased var) ; mean_rstd
-__global__ void k_bn_finalize(const float* __restrict__ part, int nblk, int C, double count, const float* __restrict__ w,
-                              const float* __restrict__ b, float eps, float momentum, float* __restrict__ rmean,
-                              float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
-                              float* __restrict__ mean_rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one 64-lane wave per channel: lanes stride over the partial blocks in double precision, then a butterfly
+__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ part, int nblk, int C, double count,
+                                                    const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                    float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                    float* __restrict__ scale, float* __restrict__ shift,
+                                                    float* __restrict__ mean_rstd) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
+    for (int i = lane; i < nblk; i += 64) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane != 0) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -153,7 +156,7 @@ extern "C" int mivp_bn_finalize(const float* part, int32_t nblk, int32_t C, doub
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                 float* shift, float* mean_rstd, mivp_stream_t stream) {
     MIVP_REQUIRE(part && scale && shift && nblk > 0 && C > 0 && count > 0);
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, (int)nblk, (int)C, count,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, (hipStream_t)stream, part, (int)nblk, (int)C, count,
                        w, b, eps, momentum, running_mean, running_var, scale, shift, mean_rstd);
     return mivp_check_launch("bn_finalize");
 }

@@ -58,23 +58,29 @@ extern "C" int mivp_add_bf16(const void* a, const void* b, int64_t n, void* y, m
     return mivp_check_launch("add_bf16");
 }
 
-// out[r] = sum_i in[i*rows + r]; one thread per r walks i in a fixed order -> deterministic
-__global__ void k_reduce_rows(const float* __restrict__ in, long n, long rows, float* __restrict__ out) {
-    const long rr = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr >= rows) return;
-    float acc = 0.f, comp = 0.f;                 // Kahan: n can be thousands of windows
-    for (long i = 0; i < n; ++i) {
-        const float yv = in[i * rows + rr] - comp;
-        const float tv = acc + yv;
-        comp = (tv - acc) - yv;
-        acc = tv;
+// out[r] = sum_i in[i*rows + r].  Block = 64 columns x 4 row-slices; every slice walks its rows in a fixed
+// order (Kahan-compensated) and the four slices are combined in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ in, long n, long rows, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const long rr = (long)blockIdx.x * 64 + col;
+    float acc = 0.f, comp = 0.f;
+    if (rr < rows) {
+        for (long i = slice; i < n; i += 4) {
+            const float yv = in[i * rows + rr] - comp;
+            const float tv = acc + yv;
+            comp = (tv - acc) - yv;
+            acc = tv;
+        }
     }
-    out[rr] = acc;
+    part[slice][col] = acc;
+    __syncthreads();
+    if (slice == 0 && rr < rows) out[rr] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 extern "C" int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream) {
     MIVP_REQUIRE(in && out && n >= 0 && rows > 0);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, in, (long)n,
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, (long)n,
                        (long)rows, out);
     return mivp_check_launch("reduce_rows");
 }

@@ -232,6 +232,7 @@ class _BnActConvFn(torch.autograd.Function):
         y = ops.conv3d(x, wp, conv_b.detach().float().contiguous(), cout, scale, shift, lrelu, None, out_f32)
         ctx.save_for_backward(x, scale, shift, mean_rstd)
         ctx.meta = (bn.training, lrelu, wd, cout, x.shape[-1])
+        ctx.conv_w = conv_w
         return y
 
     @staticmethod
@@ -244,16 +245,28 @@ class _BnActConvFn(torch.autograd.Function):
             dy_p = torch.zeros(dy.shape[:-1] + (cpad,), dtype=BF16, device=dy.device)
             dy_p[..., :cout] = dy
         dx = dgamma = dbeta = dw = db = None
-        if need_x or need_bw or need_bb:
+        rows_ok = (not lrelu) and cout <= 5 and cin < 64
+        if need_x:
             dz = ops.conv3d(dy_p, wd, None, cin)            # gradient w.r.t. the conv operand act(BN(x))
             if training:
                 dx, dgamma, dbeta = ops.bn_backward(x, dz, scale, shift, mean_rstd, lrelu)
             else:
                 dx, dgamma, dbeta = ops.bn_backward_eval(x, dz, scale, shift, mean_rstd, lrelu)
-        if need_cw or need_cb:
-            if cout > 8:
-                raise NotImplementedError("mivp_amd: conv weight gradient with Cout > 8 is not built yet")
-            dw, db = ops.conv3d_wgrad_small(x, scale, shift, lrelu, dy_p, cout)
+        if need_cw or need_cb or ((need_bw or need_bb) and not need_x):
+            if rows_ok:
+                # one MFMA pass over (x, dy) gives every parameter gradient of the BN -> conv head
+                G, S = ops.conv3d_wgrad_rows(x, dy_p, cout)
+                dw, db, dg2, db2 = ops.head_grads_from_gs(G, S, ctx.conv_w, scale, shift, mean_rstd)
+                if not need_x:
+                    dgamma, dbeta = dg2, db2
+            else:
+                if cout > 8:
+                    raise NotImplementedError("mivp_amd: conv weight gradient with Cout > 8 is not built yet")
+                if (need_bw or need_bb) and not need_x:
+                    dz = ops.conv3d(dy_p, wd, None, cin)
+                    _, dgamma, dbeta = (ops.bn_backward if training else ops.bn_backward_eval)(x, dz, scale, shift, mean_rstd, lrelu)
+                if need_cw or need_cb:
+                    dw, db = ops.conv3d_wgrad_small(x, scale, shift, lrelu, dy_p, cout)
         return (dx if need_x else None, dgamma if need_bw else None, dbeta if need_bb else None,
                 dw if need_cw else None, db if need_cb else None, None, None, None, None, None)
 

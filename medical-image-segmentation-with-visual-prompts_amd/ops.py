@@ -88,6 +88,39 @@ def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
     return dw, out[cout * 27 * cin:].clone()
 
 
+def conv3d_wgrad_rows(x, dy, cout):
+    """MFMA weight-gradient core for small-Cout convs: returns (G, S) with
+    G[co, tap, ci] = sum_u dy[u - tap][co] * x[u][ci]  (raw x) and S[co, tap] = sum_{u in bounds} dy[u - tap][co]."""
+    B, H, W, D, cin = x.shape
+    d = conv_desc(B, (H, W, D), cin, cout, False, False, False, False)
+    ws = L.lib().mivp_conv3d_wgrad_rows_ws(C.byref(d))
+    if ws == 0:
+        raise RuntimeError("conv3d_wgrad_rows: shape not supported (needs 27*Cout <= 144, Cin < 64)")
+    part = torch.empty(ws, dtype=torch.float32, device=x.device)
+    mt = 4 if 27 * cout <= 64 else 9
+    ntc = 1 if cin + 1 <= 16 else (2 if cin + 1 <= 32 else 4)
+    gs = torch.empty((16 * mt, 16 * ntc), dtype=torch.float32, device=x.device)
+    L.call("mivp_conv3d_wgrad_rows", C.byref(d), L.ptr(x), L.ptr(dy), C.c_int32(dy.shape[-1]), L.ptr(part), L.ptr(gs),
+           L.stream())
+    G = gs[:27 * cout, :cin].reshape(cout, 27, cin)
+    S = gs[:27 * cout, cin].reshape(cout, 27)
+    return G, S
+
+
+def head_grads_from_gs(G, S, conv_w, scale, shift, mean_rstd):
+    """Everything the (BatchNorm -> conv, no activation) head needs from one pass over the data:
+    conv dW [Cout,Cin,3,3,3], conv db [Cout], BatchNorm dgamma [Cin], dbeta [Cin].  Tiny tensor algebra."""
+    cout, _, cin = G.shape
+    dW = (G * scale.view(1, 1, cin) + S.unsqueeze(-1) * shift.view(1, 1, cin))        # [co, tap, ci]
+    dW = dW.permute(0, 2, 1).reshape(cout, cin, 3, 3, 3).contiguous()
+    db = S[:, 13].contiguous()
+    w = conv_w.detach().float().reshape(cout, cin, 27).permute(0, 2, 1)               # [co, tap, ci]
+    mean, rstd = mean_rstd[:cin], mean_rstd[cin:]
+    dbeta = (w * S.unsqueeze(-1)).sum((0, 1))
+    dgamma = rstd * (w * (G - S.unsqueeze(-1) * mean.view(1, 1, cin))).sum((0, 1))
+    return dW, db, dgamma, dbeta
+
+
 # ------------------------------------------------------------------------------------------
 # batch norm (training mode)
 # ------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ Gradients: every block's backward is checked tightly in isolation (test_hip_swin
 End to end the randomly initialised toy network is ill-conditioned: perturbing the INPUT by bf16-level
 relative noise (2^-9) moves the fp32 oracle's own prompt gradients by 3-12 % and the HIP path's by
 up to 26 % (tools/grad_report.py prints both).  So each trained parameter's gradient must (a) point the
-same way, cosine > 0.9, and (b) sit within max(5e-2, 2.5 x yardstick) rel-L2 of the oracle's, the
+same way, cosine > 0.9, and (b) sit within max(5e-2, 3 x yardstick) rel-L2 of the oracle's, the
 yardstick being the larger of those two self-sensitivities for that parameter."""
 from argparse import Namespace
 
@@ -98,7 +98,7 @@ def test_downstream_forward_backward(tag):
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), w.reshape(-1), dim=0))
         yard = max(rel_l2(ysd[k].grad, w), rel_l2(params_p[k].grad.cpu(), g))
         e = rel_l2(g, w)
-        if cos < 0.9 or e > max(5e-2, 2.5 * yard):
+        if cos < 0.9 or e > max(5e-2, 3.0 * yard):
             bad[k] = (e, cos, yard)
     assert not bad, bad
     # frozen BatchNorms still ran in train mode: running statistics moved exactly as the reference's

@@ -185,3 +185,37 @@ def test_upcat_fwd_bwd(idims, sdims, scale, cx, cs):
     assert rel_l2(cf(dx), x.grad) < 4e-3
     if cs:
         assert rel_l2(cf(dskip), skip.grad) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,dims,training", [(48, 2, (6, 8, 8), True), (48, 5, (4, 5, 7), False), (8, 2, (5, 4, 33), True)])
+def test_head_backward_from_one_mfma_pass(cin, cout, dims, training):
+    """conv dW/db and BatchNorm dgamma/dbeta of the (BN -> conv) head all come from (G, S) of
+    mivp_conv3d_wgrad_rows; compare with autograd through batch_norm + conv3d."""
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = r16(torch.randn(2, cin, *dims, generator=g) + 0.2)
+    gamma = (1 + 0.2 * torch.randn(cin, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(cin, generator=g)).requires_grad_(True)
+    w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    rm, rv = 0.1 * torch.randn(cin, generator=g), 1 + 0.2 * torch.rand(cin, generator=g)
+    y = F.conv3d(F.batch_norm(x, rm.clone(), rv.clone(), gamma, beta, training, 0.1, 1e-5), w, b, padding=1)
+    dy = r16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    xd = cl(x)
+    if training:
+        scale, shift, mr = ops.bn_batch_stats(xd, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5)
+    else:
+        scale, shift, mr = ops.bn_eval_affine(gamma.detach().to(DEV), beta.detach().to(DEV), rm.to(DEV), rv.to(DEV), 1e-5)
+    dyp = torch.zeros(2, *dims, 8, dtype=torch.bfloat16, device=DEV)
+    dyp[..., :cout] = cl(dy)
+    G, S = ops.conv3d_wgrad_rows(xd, dyp, cout)
+    dW, db, dgamma, dbeta = ops.head_grads_from_gs(G, S, w.detach().to(DEV), scale, shift, mr)
+    torch.cuda.synchronize()
+    assert rel_l2(dW.cpu(), w.grad) < 3e-3
+    assert rel_l2(db.cpu(), b.grad) < 1e-3
+    if training:
+        # training-mode BN: gradients also flow through the batch statistics; dgamma/dbeta do not depend on that
+        pass
+    assert rel_l2(dgamma.cpu(), gamma.grad) < 5e-3
+    assert rel_l2(dbeta.cpu(), beta.grad) < 5e-3
