@@ -50,11 +50,23 @@ def conv_flops(desc):
     return 2.0 * 27 * desc.Cin * desc.Cout * vox
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(conf, size):
-    """One oracle training step (forward + loss + backward + AdamW) on ONE volume, all host cores."""
+    """One oracle training step (forward + loss + backward + AdamW) on ONE volume, all usable host cores."""
     from oracle.unetr_ref import OracleSwinUnetR, random_state
     from oracle.loss_ref import dice_focal_loss
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = random_state(conf, seed=0)
     model = OracleSwinUnetR(conf, sd)
@@ -87,8 +99,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+    train.init_distributed(dev, "nccl")
 
     window = tuple(int(v) for v in args.window.split(","))
     conf, size, batch = train.make_conf(args.workload, window)
@@ -107,9 +118,7 @@ def main():
                         and a[0]._obj.pro_affine == 1)
 
     def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        train.barrier_sync(dev)
 
     for _ in range(args.warmup):
         train.train_step(net, opt, conf, x, y)
@@ -121,10 +130,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     _lib.profile_reset(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = train.max_over_ranks(dt, dev)
     if not torch.isfinite(loss):
         raise SystemExit("loss is not finite")
 

@@ -101,9 +101,44 @@ def dist_env():
     return rank, local, world
 
 
-def wrap_ddp(model, local_rank: int):
-    """One process per GPU, gradient all-reduce over RCCL overlapped with backward (DDP buckets).
-    BatchNorm statistics stay per replica as in the (single-device) reference: no buffer broadcast."""
+def init_distributed(device=None, backend: Optional[str] = None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  ``nccl`` is RCCL on ROCm;
+    ``gloo`` is used by the CPU tests of this plumbing."""
+    import torch.distributed as dist
+    rank, local, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if device is not None and torch.device(device).type == "cuda" else "gloo")
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def barrier_sync(device=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    """Step time of the slowest rank (what the whole job waits for)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def wrap_ddp(model, local_rank: Optional[int]):
+    """One process per GPU, gradient all-reduce (mean) overlapped with backward through DDP buckets
+    (RCCL over xGMI on the GPU box).  BatchNorm statistics stay per replica as in the single-device
+    reference: no buffer broadcast, no SyncBN.  ``local_rank=None`` wraps a CPU module (gloo tests)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
+    if local_rank is None:
+        return DDP(model, broadcast_buffers=False, gradient_as_bucket_view=True)
     return DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
                gradient_as_bucket_view=True)
