@@ -119,10 +119,11 @@ int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t*
 int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
                         mivp_stream_t stream);
 
-/* query-owner pass: dq [B*P][heads][Nqp][hd] bf16 (w.r.t. the stored, pre-scaled q) */
+/* query-owner pass: dq [B*P][heads][Nqp][hd] bf16 (w.r.t. the stored, pre-scaled q).
+ * Also WRITES delta [B*P][heads][Nqp] (= mivp_win_attn_delta) for the key-owner pass that follows. */
 int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
                          const void* kp, const void* vp, const void* qa, const void* ka,
-                         const int32_t* tok_rid, const void* d_o, const float* lse, const float* delta,
+                         const int32_t* tok_rid, const void* o, const void* d_o, const float* lse, float* delta,
                          void* dq, mivp_stream_t stream);
 
 /* key-owner pass: dk, dv [B*P][heads][Nqp][hd] bf16 for window keys;

@@ -159,20 +159,37 @@ __global__ __launch_bounds__(256) void k_win_attn_delta(MivpSwinDesc d, const bf
 }
 
 // ---------------------------------------------------------------------------------------------
-// dq pass.  grid = (B*P*heads, ceil(Nqp/64)); wave w owns query tile 4*blockIdx.y + w.
-// Keys are staged chunk by chunk: K' rows (S), V rows padded to 32 columns (dP), K^T (dq).
+// dq pass.  grid = B*P*heads; one workgroup stages the keys of its (window, head) ONCE per chunk and
+// every wave walks its own query tiles (wave + 4i) against that chunk.  LDS: K' rows (S), V rows (dP),
+// K^T (dq), key classes.  For head_dim <= 16 (DVT == 1) the dP product uses the K=16 MFMA so the V rows
+// are only 16 wide.  The pass also produces delta[q] = sum_j dO*O (needed again by the dkv pass).
 // ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+MIVP_DEV f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
 template <int DKS, int DVT>
+struct AttnBwdGeom {
+    static constexpr int DK = 32 * DKS;
+    static constexpr bool V16 = (DVT == 1);                 // head_dim <= 16: 16-wide value rows + K=16 MFMA
+    static constexpr int DVS = (DVT + 1) / 2;
+    static constexpr int DVP = V16 ? 16 : 32 * DVS;
+    static constexpr int KROW = (DK + 8) * 2;               // bytes per K'/Q' row
+    static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
+};
+
+template <int DKS, int DVT, int QPW>
 __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
-                                                         const int* __restrict__ tok_rid, const bf16_t* __restrict__ d_o,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         bf16_t* __restrict__ dq) {
+                                                         const int* __restrict__ tok_rid, const bf16_t* __restrict__ o,
+                                                         const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, bf16_t* __restrict__ dq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int DK = 32 * DKS, DVS = (DVT + 1) / 2, DVP = 32 * DVS;
-    constexpr int KROW = (DK + 8) * 2, VROWB = (DVP + 8) * 2;
+    using G = AttnBwdGeom<DKS, DVT>;
+    constexpr int DK = G::DK, DVS = G::DVS, DVP = G::DVP, KROW = G::KROW, VROWB = G::VROWB;
     const int ckeys = chunk_tiles * 16;
     const int KTROW = (ckeys + 8) * 2;
     char* Kimg = smem;
@@ -188,41 +205,31 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
     const int head = (int)(bph % heads);
     const long bp = bph / heads;
     const int pw = (int)(bp % d.P);
-    const int qt = 4 * blockIdx.y + wave;
-    const bool qlive = qt * 16 < Nqp;
-    const int qrow = qlive ? qt * 16 + r : 0;
+    const int nqt = Nqp / 16;
 
-    // per-query state (lane r)
-    const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
-    const float lse_b = lse[bph * Nqp + qrow] * LOG2E;
-    const float dl = delta[bph * Nqp + qrow];
-    bf16x8 qf[DKS], dof[DVS];
+    f32x4 dqacc[QPW][DVT];
+    float lse_b[QPW], dl[QPW];
+    int rq[QPW];
 #pragma unroll
-    for (int s = 0; s < DKS; ++s) {
-        bf16x4 piece[2];
+    for (int i = 0; i < QPW; ++i) {
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int c4 = 8 * s + 2 * g + hlf;
-            bf16x4 val = zero4();
-            if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
-            else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
-            piece[hlf] = val;
+        for (int dd = 0; dd < DVT; ++dd) dqacc[i][dd] = fzero4();
+        const int qt = wave + 4 * i;
+        const int qrow = qt < nqt ? qt * 16 + r : 0;
+        rq[i] = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        lse_b[i] = lse[bph * Nqp + qrow] * LOG2E;
+        // delta = sum_j dO * O over this head's channels: each lane covers 4g.. of every 16, then the 4 g-lanes add up
+        float acc = 0.f;
+        for (int c4 = g; c4 < hd4; c4 += 4) {
+            const bf16x4 ov = ld4(o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4));
+            const bf16x4 gv = ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += (float)ov[e] * (float)gv[e];
         }
-        qf[s] = cat44(piece[0], piece[1]);
+        acc = col_sum(acc);
+        dl[i] = acc;
+        if (qt < nqt && g == 0) delta[bph * Nqp + qrow] = acc;
     }
-#pragma unroll
-    for (int s = 0; s < DVS; ++s) {
-        bf16x4 piece[2];
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int c4 = 8 * s + 2 * g + hlf;
-            piece[hlf] = c4 < hd4 ? ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4)) : zero4();
-        }
-        dof[s] = cat44(piece[0], piece[1]);
-    }
-    f32x4 dqacc[DVT];
-#pragma unroll
-    for (int dd = 0; dd < DVT; ++dd) dqacc[dd] = fzero4();
 
     const int nt = Nkp / 16;
     const int nt_full = d.Nq / 16;
@@ -236,10 +243,8 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
             if (c4 < hd4) {
                 if (row < Nqp) val = ld4(k + ((bph * Nqp + row) * (long)hd + 4 * c4));
                 else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
-                if (c4 < 4 * DVT) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
-                }
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
             } else if (c4 < hd4 + a4) {
                 val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
             }
@@ -267,61 +272,106 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
             ridk[m] = cls;
         }
         __syncthreads();
-        if (!qlive) continue;
-        for (int u = 0; u < ntc / 2; ++u) {
-            f32x4 ds[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int lt = 2 * u + hh;
-                f32x4 s = fzero4(), dp = fzero4();
+        for (int i = 0; i < QPW; ++i) {
+            const int qt = wave + 4 * i;
+            if (qt >= nqt) continue;
+            const int qrow = qt * 16 + r;
+            bf16x8 qf[DKS];
 #pragma unroll
-                for (int ks = 0; ks < DKS; ++ks)
-                    s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * lt + r) * KROW + (32 * ks + 8 * g) * 2), qf[ks], s);
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
 #pragma unroll
-                for (int ks = 0; ks < DVS; ++ks)
-                    dp = mfma16(*reinterpret_cast<const bf16x8*>(Vimg + (size_t)(16 * lt + r) * VROWB + (32 * ks + 8 * g) * 2), dof[ks], dp);
-                const int4 kr4 = *reinterpret_cast<const int4*>(ridk + 16 * lt + 4 * g);
-                const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
-                const bool fast = (t0 + lt) < nt_full && !d.has_mask;
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf;
+                    bf16x4 val = zero4();
+                    if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
+                    else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
+                    piece[hlf] = val;
+                }
+                qf[s] = cat44(piece[0], piece[1]);
+            }
+            bf16x8 dof[DVS];
+            bf16x4 dof4 = zero4();
+            if (G::V16) {
+                if (g < hd4) dof4 = ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * g));
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float sv = s[j];
-                    bool grad = true;
-                    if (!fast) {
-                        if (krs[j] == -1) { sv = -INFINITY; grad = false; }
-                        else if (krs[j] != -2 && krs[j] != rq) { sv = 0.f; grad = false; }
+                for (int s = 0; s < DVS; ++s) {
+                    bf16x4 piece[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int c4 = 8 * s + 2 * g + hlf;
+                        piece[hlf] = c4 < hd4 ? ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4)) : zero4();
                     }
-                    const float p = __builtin_amdgcn_exp2f(sv * LOG2E - lse_b);
-                    ds[hh][j] = grad ? p * (dp[j] - dl) : 0.f;
+                    dof[s] = cat44(piece[0], piece[1]);
                 }
             }
-            const bf16x8 pb = cat44(pack4(ds[0]), pack4(ds[1]));
+            const int rqi = rq[i];
+            const float lsei = lse_b[i], dli = dl[i];
+            for (int u = 0; u < ntc / 2; ++u) {
+                f32x4 ds[2];
 #pragma unroll
-            for (int dd = 0; dd < DVT; ++dd) {
-                const char* krow = Kt + (size_t)(16 * dd + r) * KTROW;
-                const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(krow + (32 * u + 4 * g) * 2),
-                                       *reinterpret_cast<const bf16x4*>(krow + (32 * u + 16 + 4 * g) * 2));
-                dqacc[dd] = mfma16(a, pb, dqacc[dd]);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int lt = 2 * u + hh;
+                    f32x4 s = fzero4(), dp = fzero4();
+#pragma unroll
+                    for (int ks = 0; ks < DKS; ++ks)
+                        s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * lt + r) * KROW + (32 * ks + 8 * g) * 2), qf[ks], s);
+                    if (G::V16) {
+                        dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Vimg + (size_t)(16 * lt + r) * VROWB + 8 * g), dof4, dp);
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < DVS; ++ks)
+                            dp = mfma16(*reinterpret_cast<const bf16x8*>(Vimg + (size_t)(16 * lt + r) * VROWB + (32 * ks + 8 * g) * 2), dof[ks], dp);
+                    }
+                    const bool fast = (t0 + lt) < nt_full && !d.has_mask;
+                    if (fast) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ds[hh][j] = __builtin_amdgcn_exp2f(s[j] * LOG2E - lsei) * (dp[j] - dli);
+                    } else {
+                        const int4 kr4 = *reinterpret_cast<const int4*>(ridk + 16 * lt + 4 * g);
+                        const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // masked-to-zero logits and padding keys carry no gradient
+                            const bool grad = krs[j] == -2 || krs[j] == rqi;
+                            ds[hh][j] = grad ? __builtin_amdgcn_exp2f(s[j] * LOG2E - lsei) * (dp[j] - dli) : 0.f;
+                        }
+                    }
+                }
+                const bf16x8 pb = cat44(pack4(ds[0]), pack4(ds[1]));
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) {
+                    const char* krow = Kt + (size_t)(16 * dd + r) * KTROW;
+                    const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(krow + (32 * u + 4 * g) * 2),
+                                           *reinterpret_cast<const bf16x4*>(krow + (32 * u + 16 + 4 * g) * 2));
+                    dqacc[i][dd] = mfma16(a, pb, dqacc[i][dd]);
+                }
             }
         }
     }
-    if (qlive) {
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int qt = wave + 4 * i;
+        if (qt >= nqt) continue;
+        const int qrow = qt * 16 + r;
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) {
             const int j0 = 16 * dd + 4 * g;
-            if (j0 < hd) st4(dq + ((bph * Nqp + qrow) * (long)hd + j0), pack4(dqacc[dd]));
+            if (j0 < hd) st4(dq + ((bph * Nqp + qrow) * (long)hd + j0), pack4(dqacc[i][dd]));
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dkv pass.  grid = (B*P*heads, key-tile groups); wave w owns key tile kt0 + 4*blockIdx.y + w.
-// Queries are staged chunk by chunk: Q' rows (S), dO rows padded to 32 columns (dP), Q^T (dk),
-// dO^T (dv), log-sum-exp, delta, query region ids.
+// dkv pass.  grid = (B*P*heads, ksplit); the workgroup stages the queries of its (window, head) once per
+// chunk and every wave walks its own key tiles against that chunk.  LDS: Q' rows (S), dO rows (dP),
+// Q^T (dk), dO^T (dv), log-sum-exp, delta, query region ids.
 // Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT>
+template <int DKS, int DVT, int KPW>
 __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
@@ -332,8 +382,8 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
                                                           bf16_t* __restrict__ dv, float* __restrict__ dkp_part,
                                                           float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int DK = 32 * DKS, DVS = (DVT + 1) / 2, DVP = 32 * DVS;
-    constexpr int QROW = (DK + 8) * 2, OROW = (DVP + 8) * 2;
+    using G = AttnBwdGeom<DKS, DVT>;
+    constexpr int DK = G::DK, DVS = G::DVS, DVP = G::DVP, QROW = G::KROW, OROW = G::VROWB;
     const int cq = chunk_tiles * 16;
     const int TROW = (cq + 8) * 2;
     char* Qimg = smem;
@@ -352,52 +402,18 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
     const int head = (int)(bph % heads);
     const long bp = bph / heads;
     const int pw = (int)(bp % d.P);
-    const int kt = kt0 + 4 * blockIdx.y + wave;
-    const bool klive = kt * 16 < Nkp;
-    const int krow = klive ? kt * 16 + r : 0;
+    const int nt = Nkp / 16;
+    const int kstride = 4 * gridDim.y;
+    const int kfirst = kt0 + 4 * blockIdx.y + wave;
 
-    // per-key state (lane r)
-    int kcls = -1;
-    if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
-    else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
-    const bool is_prompt = krow >= Nqp;
-    bf16x8 kf[DKS], vf[DVS];
+    f32x4 dkacc[KPW][DVT], dvacc[KPW][DVT];
+    float dtok[KPW];
 #pragma unroll
-    for (int s = 0; s < DKS; ++s) {
-        bf16x4 piece[2];
+    for (int i = 0; i < KPW; ++i) {
+        dtok[i] = 0.f;
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int c4 = 8 * s + 2 * g + hlf;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (krow < Nqp) val = ld4(k + ((bph * Nqp + krow) * (long)hd + 4 * c4));
-                else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
-            } else if (c4 < hd4 + a4) {
-                val = ld4(ka + (((long)head * Nkp + krow) * A + 4 * (c4 - hd4)));
-            }
-            piece[hlf] = val;
-        }
-        kf[s] = cat44(piece[0], piece[1]);
+        for (int dd = 0; dd < DVT; ++dd) { dkacc[i][dd] = fzero4(); dvacc[i][dd] = fzero4(); }
     }
-#pragma unroll
-    for (int s = 0; s < DVS; ++s) {
-        bf16x4 piece[2];
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int c4 = 8 * s + 2 * g + hlf;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (krow < Nqp) val = ld4(v + ((bph * Nqp + krow) * (long)hd + 4 * c4));
-                else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
-            }
-            piece[hlf] = val;
-        }
-        vf[s] = cat44(piece[0], piece[1]);
-    }
-    f32x4 dkacc[DVT], dvacc[DVT];
-#pragma unroll
-    for (int dd = 0; dd < DVT; ++dd) { dkacc[dd] = fzero4(); dvacc[dd] = fzero4(); }
-    float dtok = 0.f;
 
     const int nqt = (Nqp + 31) / 32 * 2;                      // query tiles rounded to pairs
     for (int t0 = 0; t0 < nqt; t0 += chunk_tiles) {
@@ -436,78 +452,128 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
             ridq[m] = (ok && row < d.Nq) ? (d.has_mask ? tok_rid[pw * Nqp + row] : 0) : -1;   // -1: padding query row
         }
         __syncthreads();
-        if (!klive) continue;
-        for (int u = 0; u < ntc / 2; ++u) {
-            f32x4 pv[2], ds[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int lt = 2 * u + hh;
-                f32x4 s = fzero4(), dp = fzero4();
+        for (int i = 0; i < KPW; ++i) {
+            const int kt = kfirst + kstride * i;
+            if (kt >= nt) continue;
+            const int krow = kt * 16 + r;
+            int kcls = -1;
+            if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
+            else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
+            bf16x8 kf[DKS];
 #pragma unroll
-                for (int ks = 0; ks < DKS; ++ks)
-                    s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + (size_t)(16 * lt + r) * QROW + (32 * ks + 8 * g) * 2), kf[ks], s);
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
 #pragma unroll
-                for (int ks = 0; ks < DVS; ++ks)
-                    dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
-                // rows of this accumulator tile are queries 16*lt + 4g + j
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
-                const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
-                const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
-                const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
-                const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float sv = s[j];
-                    bool grad = true;
-                    if (kcls == -1) { sv = -INFINITY; grad = false; }
-                    else if (kcls != -2 && kcls != rqs[j]) { sv = 0.f; grad = false; }
-                    float p = __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]);
-                    if (rqs[j] == -1) { p = 0.f; grad = false; }           // padding query rows carry no gradient
-                    pv[hh][j] = p;
-                    const float dsv = grad ? p * (dp[j] - dls[j]) : 0.f;
-                    ds[hh][j] = dsv;
-                    dtok += dsv;
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf;
+                    bf16x4 val = zero4();
+                    if (c4 < hd4) {
+                        if (krow < Nqp) val = ld4(k + ((bph * Nqp + krow) * (long)hd + 4 * c4));
+                        else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
+                    } else if (c4 < hd4 + a4) {
+                        val = ld4(ka + (((long)head * Nkp + krow) * A + 4 * (c4 - hd4)));
+                    }
+                    piece[hlf] = val;
                 }
+                kf[s] = cat44(piece[0], piece[1]);
             }
-            const bf16x8 pb = cat44(pack4(pv[0]), pack4(pv[1]));
-            const bf16x8 sb = cat44(pack4(ds[0]), pack4(ds[1]));
+            auto vload = [&](int c4) -> bf16x4 {
+                bf16x4 val = zero4();
+                if (c4 < hd4) {
+                    if (krow < Nqp) val = ld4(v + ((bph * Nqp + krow) * (long)hd + 4 * c4));
+                    else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
+                }
+                return val;
+            };
+            bf16x8 vf[DVS];
+            bf16x4 vf4 = zero4();
+            if (G::V16) vf4 = vload(g);
+            else {
 #pragma unroll
-            for (int dd = 0; dd < DVT; ++dd) {
-                const char* qrow_t = Qt + (size_t)(16 * dd + r) * TROW;
-                const char* orow_t = Ot + (size_t)(16 * dd + r) * TROW;
-                const bf16x8 aq = cat44(*reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 4 * g) * 2),
-                                        *reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 16 + 4 * g) * 2));
-                const bf16x8 ao = cat44(*reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 4 * g) * 2),
-                                        *reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 16 + 4 * g) * 2));
-                dkacc[dd] = mfma16(aq, sb, dkacc[dd]);
-                dvacc[dd] = mfma16(ao, pb, dvacc[dd]);
+                for (int s = 0; s < DVS; ++s) vf[s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
+            }
+            for (int u = 0; u < ntc / 2; ++u) {
+                f32x4 pv[2], ds[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int lt = 2 * u + hh;
+                    f32x4 s = fzero4(), dp = fzero4();
+#pragma unroll
+                    for (int ks = 0; ks < DKS; ++ks)
+                        s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + (size_t)(16 * lt + r) * QROW + (32 * ks + 8 * g) * 2), kf[ks], s);
+                    if (G::V16) {
+                        dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Oimg + (size_t)(16 * lt + r) * OROW + 8 * g), vf4, dp);
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < DVS; ++ks)
+                            dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
+                    }
+                    // rows of this accumulator tile are queries 16*lt + 4g + j
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
+                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
+                    const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float sv = s[j];
+                        bool grad = true;
+                        if (kcls == -1) { sv = -INFINITY; grad = false; }
+                        else if (kcls != -2 && kcls != rqs[j]) { sv = 0.f; grad = false; }
+                        float p = __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]);
+                        if (rqs[j] == -1) { p = 0.f; grad = false; }           // padding query rows carry no gradient
+                        pv[hh][j] = p;
+                        const float dsv = grad ? p * (dp[j] - dls[j]) : 0.f;
+                        ds[hh][j] = dsv;
+                        dtok[i] += dsv;
+                    }
+                }
+                const bf16x8 pb = cat44(pack4(pv[0]), pack4(pv[1]));
+                const bf16x8 sb = cat44(pack4(ds[0]), pack4(ds[1]));
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) {
+                    const char* qrow_t = Qt + (size_t)(16 * dd + r) * TROW;
+                    const char* orow_t = Ot + (size_t)(16 * dd + r) * TROW;
+                    const bf16x8 aq = cat44(*reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 4 * g) * 2),
+                                            *reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 16 + 4 * g) * 2));
+                    const bf16x8 ao = cat44(*reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 4 * g) * 2),
+                                            *reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 16 + 4 * g) * 2));
+                    dkacc[i][dd] = mfma16(aq, sb, dkacc[i][dd]);
+                    dvacc[i][dd] = mfma16(ao, pb, dvacc[i][dd]);
+                }
             }
         }
     }
-    if (!klive) return;
-    dtok = col_sum(dtok);
-    if (!is_prompt) {
-        if (dk && dv) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kt = kfirst + kstride * i;
+        if (kt >= nt) continue;
+        const int krow = kt * 16 + r;
+        const float dt = col_sum(dtok[i]);
+        if (krow < Nqp) {
+            if (dk && dv) {
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) {
+                    const int j0 = 16 * dd + 4 * g;
+                    if (j0 < hd) {
+                        st4(dk + ((bph * Nqp + krow) * (long)hd + j0), pack4(dkacc[i][dd]));
+                        st4(dv + ((bph * Nqp + krow) * (long)hd + j0), pack4(dvacc[i][dd]));
+                    }
+                }
+            }
+        } else if (krow < Nqp + d.Npp) {
+            const int t = krow - Nqp;
 #pragma unroll
             for (int dd = 0; dd < DVT; ++dd) {
                 const int j0 = 16 * dd + 4 * g;
                 if (j0 < hd) {
-                    st4(dk + ((bph * Nqp + krow) * (long)hd + j0), pack4(dkacc[dd]));
-                    st4(dv + ((bph * Nqp + krow) * (long)hd + j0), pack4(dvacc[dd]));
+                    *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dkacc[i][dd];
+                    *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dvacc[i][dd];
                 }
             }
+            if (g == 0) dtok_part[bph * d.Npp + t] = dt;
         }
-    } else if (krow < Nqp + d.Npp) {
-        const int t = krow - Nqp;
-#pragma unroll
-        for (int dd = 0; dd < DVT; ++dd) {
-            const int j0 = 16 * dd + 4 * g;
-            if (j0 < hd) {
-                *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dkacc[dd];
-                *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + t) * (long)hd + j0)) = dvacc[dd];
-            }
-        }
-        if (g == 0) dtok_part[bph * d.Npp + t] = dtok;
     }
 }
 
@@ -719,63 +785,74 @@ static int pick_chunk(int total_tiles, size_t fixed_bytes, size_t bytes_per_tile
     c &= ~1;
     if (c > total_tiles) c = total_tiles;
     if (c < 2) c = 2;
-    return c;
+    // balance the chunks: smallest even chunk size that needs the same number of passes
+    const int passes = (total_tiles + c - 1) / c;
+    int bal = (total_tiles + passes - 1) / passes;
+    bal = (bal + 1) & ~1;
+    return bal < c ? bal : c;
 }
+
+static constexpr size_t ATTN_BWD_LDS_BUDGET = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
 
 template <int DKS, int DVT>
 static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
-                     const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
-                     const float* delta, void* dq, hipStream_t st) {
-    constexpr int DK = 32 * DKS, DVP = 32 * ((DVT + 1) / 2);
-    const size_t per_tile = 16 * (size_t)(DK + 8) * 2 + 16 * (size_t)(DVP + 8) * 2 + (size_t)16 * DVT * 32 + 64;
+                     const void* qa, const void* ka, const int32_t* tok_rid, const void* o, const void* d_o,
+                     const float* lse, float* delta, void* dq, hipStream_t st) {
+    using G = AttnBwdGeom<DKS, DVT>;
+    constexpr int QPW = 6;
+    if (d->Nqp / 16 > 4 * QPW) { mivp_set_error("win_attn_bwd_dq: more than 384 queries per window"); return MIVP_EUNSUPPORTED; }
+    const size_t per_tile = 16 * (size_t)G::KROW + 16 * (size_t)G::VROWB + (size_t)16 * DVT * 32 + 64;
     const size_t fixed = (size_t)16 * DVT * 16;
     const int nt = d->Nkp / 16;
-    const int chunk = pick_chunk(nt, fixed, per_tile, 64 * 1024);
+    const int chunk = pick_chunk(nt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
-    dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)((d->Nqp / 16 + 3) / 4));
-    hipLaunchKernelGGL((k_win_attn_bwd_dq<DKS, DVT>), grid, dim3(256), lds, st, *d, chunk, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid,
-                       (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
+    auto kern = k_win_attn_bwd_dq<DKS, DVT, QPW>;
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(256), lds, st, *d, chunk, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
+                       (const bf16_t*)ka, tok_rid, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
     return mivp_check_launch("win_attn_bwd_dq");
 }
 
 extern "C" int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                                     const void* vp, const void* qa, const void* ka, const int32_t* tok_rid,
-                                    const void* d_o, const float* lse, const float* delta, void* dq,
+                                    const void* o, const void* d_o, const float* lse, float* delta, void* dq,
                                     mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
-    MIVP_REQUIRE(q && k && v && qa && ka && d_o && lse && delta && dq);
+    MIVP_REQUIRE(q && k && v && qa && ka && o && d_o && lse && delta && dq);
     MIVP_REQUIRE(d->Np == 0 || (kp && vp));
     MIVP_REQUIRE(!d->has_mask || tok_rid);
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dq: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (dks == 1) return launch_dq<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
-    if (dks == 2) return launch_dq<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
-    return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dq, st);
+    if (dks == 1) return launch_dq<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
+    if (dks == 2) return launch_dq<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
+    return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
 }
 
-template <int DKS, int DVT>
+template <int DKS, int DVT, int KPW>
 static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
                       const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
                       const float* delta, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
                       hipStream_t st) {
-    constexpr int DK = 32 * DKS, DVP = 32 * ((DVT + 1) / 2);
-    const size_t per_tile = 16 * (size_t)(DK + 8) * 2 + 16 * (size_t)(DVP + 8) * 2 + 2 * (size_t)16 * DVT * 32 + 3 * 64;
+    using G = AttnBwdGeom<DKS, DVT>;
+    const size_t per_tile = 16 * (size_t)G::KROW + 16 * (size_t)G::VROWB + 2 * (size_t)16 * DVT * 32 + 3 * 64;
     const size_t fixed = 2 * (size_t)16 * DVT * 16;
     const int nqt = (d->Nqp + 31) / 32 * 2;
-    const int chunk = pick_chunk(nqt, fixed, per_tile, 64 * 1024);
+    const int chunk = pick_chunk(nqt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
     const int nt = d->Nkp / 16;
     const int kt0 = (dk && dv) ? 0 : d->Nqp / 16;            // prompt-only mode skips the window keys
     const int ktiles = nt - kt0;
     if (ktiles <= 0) return MIVP_OK;
-    dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)((ktiles + 3) / 4));
-    hipLaunchKernelGGL((k_win_attn_bwd_dkv<DKS, DVT>), grid, dim3(256), lds, st, *d, chunk, kt0, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
-                       (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part,
-                       dvp_part, dtok_part);
+    const int ksplit = (ktiles + 4 * KPW - 1) / (4 * KPW);
+    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW>;
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o,
+                       lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part, dvp_part, dtok_part);
     return mivp_check_launch("win_attn_bwd_dkv");
 }
 
@@ -792,9 +869,9 @@ extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (dks == 1) return launch_dkv<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    if (dks == 2) return launch_dkv<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    return launch_dkv<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    if (dks == 1) return launch_dkv<1, 1, 7>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    if (dks == 2) return launch_dkv<2, 2, 6>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    return launch_dkv<3, 3, 4>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
 }
 
 extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x,

@@ -162,15 +162,17 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
     L.call("mivp_swin_proj_mlp_bwd", C.byref(d), L.ptr(dy), L.ptr(tb.tok_dst), L.ptr(sv.t1), L.ptr(w.ln2_w), L.ptr(w.ln2_b),
            L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), st)
     delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
-    L.call("mivp_win_attn_delta", C.byref(d), L.ptr(sv.o), L.ptr(d_o), L.ptr(delta), st)
     dx = dprompt = dts = None
     dk = dv = None
     if need_dx:
-        dq = torch.empty_like(sv.q)
+        dq = torch.empty_like(sv.q)                      # the dq pass also writes delta for the dkv pass
         L.call("mivp_win_attn_bwd_dq", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
-               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dq), st)
+               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta),
+               L.ptr(dq), st)
         dk = torch.empty_like(sv.k)
         dv = torch.empty_like(sv.v)
+    else:
+        L.call("mivp_win_attn_delta", C.byref(d), L.ptr(sv.o), L.ptr(d_o), L.ptr(delta), st)
     has_prompt = d.Np > 0
     dkp_part = dvp_part = dtok_part = None
     if has_prompt and need_prompt:
