@@ -47,6 +47,20 @@ MIVP_DEV bf16x8 cat44(bf16x4 lo, bf16x4 hi) {
 MIVP_DEV float col_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 MIVP_DEV float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v; }
 
+// Attention logit classes (branch-free: these compile to v_cmp + v_cndmask, never to exec-mask branches).
+//   key class  -1: padding key, excluded from the softmax (logit -> -inf)
+//              -2: prompt key, always attended
+//            >= 0: region id; the logit survives only where it equals the query's region id, otherwise
+//                  the reference's multiplicative mask forces it to 0 (window_attention.py:54-56)
+// `live` is false where the logit is a constant (masked or excluded), i.e. where it carries no gradient.
+MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live) {
+    const bool excl = kcls == -1;
+    const bool match = (kcls == -2) | (kcls == rq);
+    live = match & !excl;
+    const float v = match ? s : 0.f;
+    return excl ? -INFINITY : v;
+}
+
 // error plumbing shared by the C-ABI translation units
 void mivp_set_error(const char* msg);
 int mivp_check_launch(const char* what);

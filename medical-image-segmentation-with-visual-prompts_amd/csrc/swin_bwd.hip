@@ -179,8 +179,8 @@ struct AttnBwdGeom {
     static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
 };
 
-template <int DKS, int DVT, int QPW>
-__global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
+template <int DKS, int DVT, int QPW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
     for (int i = 0; i < QPW; ++i) {
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) dqacc[i][dd] = fzero4();
-        const int qt = wave + 4 * i;
+        const int qt = wave + NW * i;
         const int qrow = qt < nqt ? qt * 16 + r : 0;
         rq[i] = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
         lse_b[i] = lse[bph * Nqp + qrow] * LOG2E;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
         const int ntc = (nt - t0) < chunk_tiles ? (nt - t0) : chunk_tiles;       // tiles in this chunk (even)
         const int key0 = t0 * 16, nkeys = ntc * 16;
         __syncthreads();
-        for (int e = tid; e < nkeys * dk4; e += 256) {
+        for (int e = tid; e < nkeys * dk4; e += 64 * NW) {
             const int lrow = e / dk4, c4 = e - lrow * dk4, row = key0 + lrow;
             bf16x4 val = zero4();
             if (c4 < hd4) {
@@ -251,11 +251,11 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
             *reinterpret_cast<bf16x4*>(Kimg + (size_t)lrow * KROW + 8 * c4) = val;
         }
         // K^T rows between hd and 16*DVT must be zero (they multiply dS in the dq MFMA)
-        for (int e = tid; e < (16 * DVT - hd) * nkeys; e += 256) {
+        for (int e = tid; e < (16 * DVT - hd) * nkeys; e += 64 * NW) {
             const int rr = hd + e / nkeys, col = e % nkeys;
             *reinterpret_cast<bf16_t*>(Kt + (size_t)rr * KTROW + 2 * col) = (bf16_t)0.0f;
         }
-        for (int e = tid; e < nkeys * dvp4; e += 256) {
+        for (int e = tid; e < nkeys * dvp4; e += 64 * NW) {
             const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = key0 + lrow;
             bf16x4 val = zero4();
             if (c4 < hd4) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
             }
             *reinterpret_cast<bf16x4*>(Vimg + (size_t)lrow * VROWB + 8 * c4) = val;
         }
-        for (int m = tid; m < nkeys; m += 256) {
+        for (int m = tid; m < nkeys; m += 64 * NW) {
             const int row = key0 + m;
             int cls = -1;
             if (row < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + row] : 0;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
-            const int qt = wave + 4 * i;
+            const int qt = wave + NW * i;
             if (qt >= nqt) continue;
             const int qrow = qt * 16 + r;
             bf16x8 qf[DKS];
@@ -335,8 +335,10 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             // masked-to-zero logits and padding keys carry no gradient
-                            const bool grad = krs[j] == -2 || krs[j] == rqi;
-                            ds[hh][j] = grad ? __builtin_amdgcn_exp2f(s[j] * LOG2E - lsei) * (dp[j] - dli) : 0.f;
+                            bool live;
+                            const float sv = classify_logit(s[j], krs[j], rqi, live);
+                            const float val = __builtin_amdgcn_exp2f(sv * LOG2E - lsei) * (dp[j] - dli);
+                            ds[hh][j] = live ? val : 0.f;
                         }
                     }
                 }
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
     }
 #pragma unroll
     for (int i = 0; i < QPW; ++i) {
-        const int qt = wave + 4 * i;
+        const int qt = wave + NW * i;
         if (qt >= nqt) continue;
         const int qrow = qt * 16 + r;
 #pragma unroll
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dq(MivpSwinDesc d, int chu
 // Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int KPW>
-__global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
+template <int DKS, int DVT, int KPW, int NW>
+__global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
                                                           const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
     const long bp = bph / heads;
     const int pw = (int)(bp % d.P);
     const int nt = Nkp / 16;
-    const int kstride = 4 * gridDim.y;
-    const int kfirst = kt0 + 4 * blockIdx.y + wave;
+    const int kstride = NW * gridDim.y;
+    const int kfirst = kt0 + NW * blockIdx.y + wave;
 
     f32x4 dkacc[KPW][DVT], dvacc[KPW][DVT];
     float dtok[KPW];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
         const int ntc = (nqt - t0) < chunk_tiles ? (nqt - t0) : chunk_tiles;
         const int q0 = t0 * 16, nq = ntc * 16;
         __syncthreads();
-        for (int e = tid; e < nq * dk4; e += 256) {
+        for (int e = tid; e < nq * dk4; e += 64 * NW) {
             const int lrow = e / dk4, c4 = e - lrow * dk4, row = q0 + lrow;
             bf16x4 val = zero4();
             if (row < Nqp) {
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
             }
             *reinterpret_cast<bf16x4*>(Qimg + (size_t)lrow * QROW + 8 * c4) = val;
         }
-        for (int e = tid; e < nq * dvp4; e += 256) {
+        for (int e = tid; e < nq * dvp4; e += 64 * NW) {
             const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
             bf16x4 val = zero4();
             if (row < Nqp && c4 < hd4) val = ld4(d_o + ((bp * Nqp + row) * (long)C + head * hd + 4 * c4));
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
             }
             *reinterpret_cast<bf16x4*>(Oimg + (size_t)lrow * OROW + 8 * c4) = val;
         }
-        for (int m = tid; m < nq; m += 256) {
+        for (int m = tid; m < nq; m += 64 * NW) {
             const int row = q0 + m;
             const bool ok = row < Nqp;
             lse_s[m] = ok ? lse[bph * Nqp + row] * LOG2E : 0.f;
@@ -517,14 +519,12 @@ __global__ __launch_bounds__(256) void k_win_attn_bwd_dkv(MivpSwinDesc d, int ch
                     const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float sv = s[j];
-                        bool grad = true;
-                        if (kcls == -1) { sv = -INFINITY; grad = false; }
-                        else if (kcls != -2 && kcls != rqs[j]) { sv = 0.f; grad = false; }
-                        float p = __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]);
-                        if (rqs[j] == -1) { p = 0.f; grad = false; }           // padding query rows carry no gradient
+                        bool live;
+                        const float sv = classify_logit(s[j], kcls, rqs[j], live);
+                        const bool qok = rqs[j] != -1;                      // padding query rows: no P, no gradient
+                        const float p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
+                        const float dsv = (live & qok) ? p * (dp[j] - dls[j]) : 0.f;
                         pv[hh][j] = p;
-                        const float dsv = grad ? p * (dp[j] - dls[j]) : 0.f;
                         ds[hh][j] = dsv;
                         dtok[i] += dsv;
                     }
@@ -799,16 +799,16 @@ static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const 
                      const void* qa, const void* ka, const int32_t* tok_rid, const void* o, const void* d_o,
                      const float* lse, float* delta, void* dq, hipStream_t st) {
     using G = AttnBwdGeom<DKS, DVT>;
-    constexpr int QPW = 6;
-    if (d->Nqp / 16 > 4 * QPW) { mivp_set_error("win_attn_bwd_dq: more than 384 queries per window"); return MIVP_EUNSUPPORTED; }
+    constexpr int NW = 8, QPW = 3;
+    if (d->Nqp / 16 > NW * QPW) { mivp_set_error("win_attn_bwd_dq: more than 384 queries per window"); return MIVP_EUNSUPPORTED; }
     const size_t per_tile = 16 * (size_t)G::KROW + 16 * (size_t)G::VROWB + (size_t)16 * DVT * 32 + 64;
     const size_t fixed = (size_t)16 * DVT * 16;
     const int nt = d->Nkp / 16;
     const int chunk = pick_chunk(nt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
-    auto kern = k_win_attn_bwd_dq<DKS, DVT, QPW>;
+    auto kern = k_win_attn_bwd_dq<DKS, DVT, QPW, NW>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(256), lds, st, *d, chunk, (const bf16_t*)q,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, st, *d, chunk, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
                        (const bf16_t*)ka, tok_rid, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
     return mivp_check_launch("win_attn_bwd_dq");
@@ -846,11 +846,12 @@ static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const
     const int kt0 = (dk && dv) ? 0 : d->Nqp / 16;            // prompt-only mode skips the window keys
     const int ktiles = nt - kt0;
     if (ktiles <= 0) return MIVP_OK;
-    const int ksplit = (ktiles + 4 * KPW - 1) / (4 * KPW);
-    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW>;
+    constexpr int NW = 8;
+    const int ksplit = (ktiles + NW * KPW - 1) / (NW * KPW);
+    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o,
                        lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part, dvp_part, dtok_part);
     return mivp_check_launch("win_attn_bwd_dkv");
@@ -869,9 +870,9 @@ extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (dks == 1) return launch_dkv<1, 1, 7>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    if (dks == 2) return launch_dkv<2, 2, 6>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    return launch_dkv<3, 3, 4>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    if (dks == 1) return launch_dkv<1, 1, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    if (dks == 2) return launch_dkv<2, 2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+    return launch_dkv<3, 3, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
 }
 
 extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x,

@@ -195,20 +195,23 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1b  window attention forward, one workgroup per (window instance, head)
+// K1b  window attention forward, one workgroup (8 waves) per (window instance, head)
 //   LDS: K' image [Nkp][DK+8] (rows = head dims | bias aug | zero pad), V^T image [16*DVT][Nkp+8],
-//        key region ids.  Q' fragments are assembled per query tile straight from global.
-//   Each wave walks 16-query tiles; S^T = K' Q'^T puts ONE query on each lane, so the softmax
-//   row reductions are in-lane + 2 shuffles and P feeds the PV MFMA with no lane movement
-//   (k index permuted identically on both operands).
+//        key classes.  Q' fragments are assembled per query tile straight from global.
+//   Each wave walks 16-query tiles; S^T = K' Q'^T puts ONE query on each lane, so the softmax row
+//   reductions are in-lane + 2 shuffles and P feeds the PV MFMA with no lane movement (k index
+//   permuted identically on both operands).  Keys are consumed 32 at a time with an online softmax
+//   (running max / sum, O rescaled by exp(m_old - m_new)): only two score tiles are live, which
+//   keeps the kernel under 128 VGPRs so that 16+ waves per CU hide the LDS / MFMA / exp latency
+//   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
-template <int NT, int DKS, int DVT>
-__global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
-                                                      const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                      const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
-                                                      const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
-                                                      const int* __restrict__ tok_rid, bf16_t* __restrict__ o,
-                                                      float* __restrict__ lse) {
+template <int DKS, int DVT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+                                                         const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                         const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
+                                                         const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
+                                                         const int* __restrict__ tok_rid, bf16_t* __restrict__ o,
+                                                         float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DK = 32 * DKS;
     constexpr int KROW = (DK + 8) * 2;                       // bytes
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
     const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4;
 
     // ---- stage K' ----
-    for (int e = tid; e < Nkp * dk4; e += 256) {
+    for (int e = tid; e < Nkp * dk4; e += 64 * NW) {
         const int row = e / dk4, c4 = e - row * dk4;
         bf16x4 val = zero4();
         if (c4 < hd4) {
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
         *reinterpret_cast<bf16x4*>(Kimg + (size_t)row * KROW + 8 * c4) = val;
     }
     // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows) ----
-    for (int e = tid; e < Nkp * (4 * DVT); e += 256) {
+    for (int e = tid; e < Nkp * (4 * DVT); e += 64 * NW) {
         const int row = e / (4 * DVT), c4 = e - row * (4 * DVT);
         bf16x4 val = zero4();
         if (c4 < hd4) {
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<bf16_t*>(Vt + (size_t)(4 * c4 + i) * VROW + 2 * row) = val[i];
     }
-    // ---- key classes: -1 excluded, -2 always attended (prompt), else region id ----
-    for (int m = tid; m < Nkp; m += 256) {
+    // ---- key classes (classify_logit in common.hpp) ----
+    for (int m = tid; m < Nkp; m += 64 * NW) {
         int cls = -1;
         if (m < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + m] : 0;
         else if (m >= Nqp && m < Nqp + d.Np) cls = -2;
@@ -261,11 +264,11 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
     }
     __syncthreads();
 
-    // NT = Nkp / 16 key tiles (even), a template parameter so every S tile lives in fixed registers
+    const int npairs = Nkp / 32;                             // key tiles come in pairs (Nkp % 32 == 0)
     const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
     const float LOG2E = 1.4426950408889634f;
 
-    for (int qt = wave; qt < Nqp / 16; qt += 4) {
+    for (int qt = wave; qt < Nqp / 16; qt += NW) {
         const int qrow = qt * 16 + r;
         const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
         // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
@@ -283,18 +286,20 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
             }
             qf[s] = cat44(piece[0], piece[1]);
         }
-
-        f32x4 S[NT];
-        float mx = -INFINITY;
+        f32x4 oacc[DVT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            {
+        for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
+        float mrun = -INFINITY, lsum = 0.f;                  // mrun already multiplied by log2(e)
+
+        for (int u = 0; u < npairs; ++u) {
+            f32x4 sv[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int t = 2 * u + hh;
                 f32x4 acc = fzero4();
 #pragma unroll
-                for (int s = 0; s < DKS; ++s) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * t + r) * KROW + (32 * s + 8 * g) * 2);
-                    acc = mfma16(a, qf[s], acc);
-                }
+                for (int s = 0; s < DKS; ++s)
+                    acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * t + r) * KROW + (32 * s + 8 * g) * 2), qf[s], acc);
                 if (t < nt_full) {
                     if (d.has_mask) {
                         const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
@@ -305,56 +310,43 @@ __global__ __launch_bounds__(256) void k_win_attn_fwd(MivpSwinDesc d, const bf16
                     }
                 } else {
                     const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
-                    const int krs[4] = {kr.x, kr.y, kr.z, kr.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (krs[j] == -1) acc[j] = -INFINITY;
-                        else if (krs[j] != -2 && krs[j] != rq) acc[j] = 0.f;
-                    }
+                    bool live;
+                    acc[0] = classify_logit(acc[0], kr.x, rq, live);
+                    acc[1] = classify_logit(acc[1], kr.y, rq, live);
+                    acc[2] = classify_logit(acc[2], kr.z, rq, live);
+                    acc[3] = classify_logit(acc[3], kr.w, rq, live);
                 }
-                S[t] = acc;
-                mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                sv[hh] = acc * LOG2E;
             }
-        }
-        mx = col_max(mx);
-        const float mb = mx * LOG2E;
-        float lsum = 0.f;
+            float pmax = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                               fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+            pmax = col_max(pmax);
+            const float mnew = fmaxf(mrun, pmax);            // the first pair always holds valid content keys: finite
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+            float psum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            {
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(S[t][j] * LOG2E - mb);
-                    S[t][j] = p;
-                    lsum += p;
-                }
+                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(sv[hh][j] - mnew); sv[hh][j] = p; psum += p; }
+            lsum = lsum * alpha + psum;
+            const bf16x8 pb = cat44(pack4(sv[0]), pack4(sv[1]));
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd) {
+                const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
+                const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
+                                       *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
+                oacc[dd] = mfma16(a, pb, oacc[dd] * alpha);
             }
         }
         lsum = col_sum(lsum);
-
-        f32x4 oacc[DVT];
-#pragma unroll
-        for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
-#pragma unroll
-        for (int u = 0; u < NT / 2; ++u) {
-            {
-                const bf16x8 pb = cat44(pack4(S[2 * u]), pack4(S[2 * u + 1]));
-#pragma unroll
-                for (int dd = 0; dd < DVT; ++dd) {
-                    const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
-                    const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
-                                           *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
-                    oacc[dd] = mfma16(a, pb, oacc[dd]);
-                }
-            }
-        }
         const float inv = 1.0f / lsum;
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) {
             const int j0 = 16 * dd + 4 * g;
             if (j0 < hd) st4(o + ((bp * Nqp + qrow) * (long)C + head * hd + j0), pack4(oacc[dd] * inv));
         }
-        if (g == 0) lse[bph * Nqp + qrow] = mx + logf(lsum);
+        if (g == 0) lse[bph * Nqp + qrow] = (mrun + __builtin_amdgcn_logf(lsum)) * 0.6931471805599453f;
     }
 }
 
@@ -532,20 +524,21 @@ extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const f
     return mivp_check_launch("relbias_aug");
 }
 
-template <int NT, int DKS, int DVT>
+template <int DKS, int DVT>
 static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                            const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
                            hipStream_t st) {
+    constexpr int NW = 8;
     const size_t krow = (32 * DKS + 8) * 2, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
-    auto kern = k_win_attn_fwd<NT, DKS, DVT>;
+    auto kern = k_win_attn_fwd<DKS, DVT, NW>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
     }
     const unsigned grid = (unsigned)((long)d->B * d->P * d->heads);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse);
     return mivp_check_launch("win_attn_fwd");
 }
@@ -560,7 +553,7 @@ int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt) {
     *dks = ks;
     *nt = d->Nkp / 16;
     if (ks > 3) return MIVP_EUNSUPPORTED;
-    switch (*nt) { case 2: case 4: case 16: case 20: case 22: case 26: return MIVP_OK; default: return MIVP_EUNSUPPORTED; }
+    return MIVP_OK;
 }
 
 extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
@@ -574,12 +567,9 @@ extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const voi
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_fwd: head_dim / key count outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-#define ATT(N, K) return launch_attn_fwd<N, K, K>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st)
-#define ATTN(N) if (nt == N) { if (dks == 1) ATT(N, 1); if (dks == 2) ATT(N, 2); ATT(N, 3); }
-    ATTN(2) ATTN(4) ATTN(16) ATTN(20) ATTN(22) ATTN(26)
-#undef ATTN
-#undef ATT
-    return MIVP_EUNSUPPORTED;
+    if (dks == 1) return launch_attn_fwd<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    if (dks == 2) return launch_attn_fwd<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    return launch_attn_fwd<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
 }
 
 extern "C" int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x, const int32_t* tok_src,

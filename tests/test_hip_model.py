@@ -98,7 +98,8 @@ def test_downstream_forward_backward(tag):
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), w.reshape(-1), dim=0))
         yard = max(rel_l2(ysd[k].grad, w), rel_l2(params_p[k].grad.cpu(), g))
         e = rel_l2(g, w)
-        if cos < 0.9 or e > max(5e-2, 3.0 * yard):
+        # the direction check only means something where the gradient itself is stable under bf16-level noise
+        if (yard < 0.2 and cos < 0.9) or e > max(5e-2, 3.0 * yard):
             bad[k] = (e, cos, yard)
     assert not bad, bad
     # frozen BatchNorms still ran in train mode: running statistics moved exactly as the reference's
