@@ -164,17 +164,21 @@ extern "C" int mivp_bn_finalize(const float* part, int32_t nblk, int32_t C, doub
 __global__ __launch_bounds__(256) void k_affine_act(const bf16_t* __restrict__ x, long n_vox, int C,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     int lrelu, bf16_t* __restrict__ y) {
+    // the launch guarantees (gridDim.x * 256) % (C/8) == 0: a thread keeps one channel group, constants in registers
     const int G = C / 8;
     const long items = n_vox * G;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[cg * 8 + i]; sh[i] = shift[cg * 8 + i]; }
     for (long it = gtid; it < items; it += stride) {
-        const int cg = (int)(it % G);
         const bf16x8 v = ld8(x + it * 8);
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float f = (float)v[i] * scale[cg * 8 + i] + shift[cg * 8 + i];
+            float f = (float)v[i] * sc[i] + sh[i];
             if (lrelu) f = f > 0.f ? f : 0.01f * f;
             o[i] = (bf16_t)f;
         }
@@ -182,11 +186,22 @@ __global__ __launch_bounds__(256) void k_affine_act(const bf16_t* __restrict__ x
     }
 }
 
+// number of 256-thread blocks such that (blocks * 256) % G == 0 (every thread keeps one channel group)
+static unsigned fixed_group_grid(long items, int G, long cap) {
+    long want = (items + 255) / 256;
+    if (want > cap) want = cap;
+    long a = G, b = 256;
+    while (b) { const long t = a % b; a = b; b = t; }       // a = gcd(G, 256)
+    const long step = G / a;
+    long blocks = want / step * step;
+    if (blocks < step) blocks = step;
+    return (unsigned)blocks;
+}
+
 extern "C" int mivp_affine_act(const void* x, int64_t n_vox, int32_t C, const float* scale, const float* shift,
                                int32_t lrelu, void* y, mivp_stream_t stream) {
     MIVP_REQUIRE(x && y && scale && shift && n_vox > 0 && C % 8 == 0);
-    const long items = n_vox * (C / 8);
-    const unsigned grid = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    const unsigned grid = fixed_group_grid(n_vox * (C / 8), C / 8, 4096);
     hipLaunchKernelGGL(k_affine_act, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)n_vox, (int)C,
                        scale, shift, (int)lrelu, (bf16_t*)y);
     return mivp_check_launch("affine_act");
@@ -249,23 +264,33 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const bf16_t* __restrict__
                                                       long n_vox, int C, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ sums, int lrelu, bf16_t* __restrict__ dx) {
+    // fixed channel group per thread (see k_affine_act): dx = a*gz + b*x + c with per-channel a, b, c
     const int G = C / 8;
     const long items = n_vox * G;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
     const float inv_n = 1.0f / (float)n_vox;
+    float sc[8], sh[8], ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        sc[i] = scale[c]; sh[i] = shift[c];
+        const float mu = mean_rstd[c], rs = mean_rstd[C + c];
+        const float k2 = sums[C + c] * inv_n * rs;          // xhat * S2/n = (x - mu) * k2
+        ca[i] = sc[i];
+        cb[i] = -sc[i] * k2;
+        cc[i] = sc[i] * (mu * k2 - sums[c] * inv_n);
+    }
     for (long it = gtid; it < items; it += stride) {
-        const int cg = (int)(it % G);
         const bf16x8 xv = ld8(x + it * 8), gv = ld8(dy + it * 8);
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c = cg * 8 + i;
             const float xf = (float)xv[i];
             float gz = (float)gv[i];
-            if (lrelu && xf * scale[c] + shift[c] <= 0.f) gz *= 0.01f;
-            const float xhat = (xf - mean_rstd[c]) * mean_rstd[C + c];
-            o[i] = (bf16_t)(scale[c] * (gz - sums[c] * inv_n - xhat * sums[C + c] * inv_n));
+            if (lrelu && xf * sc[i] + sh[i] <= 0.f) gz *= 0.01f;
+            o[i] = (bf16_t)(ca[i] * gz + cb[i] * xf + cc[i]);
         }
         st8(dx + it * 8, o);
     }
@@ -275,8 +300,7 @@ extern "C" int mivp_bn_bwd_apply(const void* x, const void* dy, int64_t n_vox, i
                                  const float* shift, const float* mean_rstd, const float* sums, int32_t lrelu, void* dx,
                                  mivp_stream_t stream) {
     MIVP_REQUIRE(x && dy && scale && shift && mean_rstd && sums && dx && n_vox > 0 && C % 8 == 0);
-    const long items = n_vox * (C / 8);
-    const unsigned grid = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    const unsigned grid = fixed_group_grid(n_vox * (C / 8), C / 8, 4096);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy,
                        (long)n_vox, (int)C, scale, shift, mean_rstd, sums, (int)lrelu, (bf16_t*)dx);
     return mivp_check_launch("bn_bwd_apply");

@@ -58,29 +58,31 @@ extern "C" int mivp_add_bf16(const void* a, const void* b, int64_t n, void* y, m
     return mivp_check_launch("add_bf16");
 }
 
-// out[r] = sum_i in[i*rows + r].  Block = 64 columns x 4 row-slices; every slice walks its rows in a fixed
-// order (Kahan-compensated) and the four slices are combined in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ in, long n, long rows, float* __restrict__ out) {
-    __shared__ float part[4][64];
-    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const long rr = (long)blockIdx.x * 64 + col;
-    float acc = 0.f, comp = 0.f;
+// out[r] = sum_i in[i*rows + r].  Block = 32 columns x 32 row-slices (1024 threads): a slice walks rows
+// slice, slice+32, ... in a fixed order, then the 32 slice sums are combined by a fixed-shape tree in LDS:
+// deterministic, and rows/32 blocks keep enough CUs busy for the [1372 x 3072] prompt-gradient partials.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ in, long n, long rows, float* __restrict__ out) {
+    __shared__ float part[32][33];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const long rr = (long)blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
     if (rr < rows) {
-        for (long i = slice; i < n; i += 4) {
-            const float yv = in[i * rows + rr] - comp;
-            const float tv = acc + yv;
-            comp = (tv - acc) - yv;
-            acc = tv;
-        }
+        long i = slice;
+        for (; i + 32 < n; i += 64) { a0 += in[i * rows + rr]; a1 += in[(i + 32) * rows + rr]; }
+        if (i < n) a0 += in[i * rows + rr];
     }
-    part[slice][col] = acc;
+    part[slice][col] = a0 + a1;
     __syncthreads();
-    if (slice == 0 && rr < rows) out[rr] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    for (int h = 16; h > 0; h >>= 1) {
+        if (slice < h) part[slice][col] += part[slice + h][col];
+        __syncthreads();
+    }
+    if (slice == 0 && rr < rows) out[rr] = part[0][col];
 }
 
 extern "C" int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream) {
     MIVP_REQUIRE(in && out && n >= 0 && rows > 0);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, (long)n,
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, in, (long)n,
                        (long)rows, out);
     return mivp_check_launch("reduce_rows");
 }

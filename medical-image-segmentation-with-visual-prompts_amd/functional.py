@@ -229,7 +229,10 @@ class _BnActConvFn(torch.autograd.Function):
         else:
             scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
         cout = conv_w.shape[0]
-        y = ops.conv3d(x, wp, conv_b.detach().float().contiguous(), cout, scale, shift, lrelu, None, out_f32)
+        # one elementwise pass applies BatchNorm affine + activation; the conv then streams plain bf16 operands
+        # (applying them inside the conv's operand load costs ~100 VALU ops per k-step, 27x per voxel)
+        xa = ops.affine_act(x, scale, shift, lrelu)
+        y = ops.conv3d(xa, wp, conv_b.detach().float().contiguous(), cout, None, None, False, None, out_f32)
         ctx.save_for_backward(x, scale, shift, mean_rstd)
         ctx.meta = (bn.training, lrelu, wd, cout, x.shape[-1])
         ctx.conv_w = conv_w
