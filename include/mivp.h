@@ -187,7 +187,11 @@ typedef struct MivpConvDesc {
  * rows >= Cout and columns >= 27*Cin zero (Cout_p = Cout rounded up to 16) ; bias [Cout] f32 or NULL */
 int mivp_conv3d_fwd(const MivpConvDesc* d, const void* x, const void* w, const float* bias,
                     const float* scale, const float* shift, const void* residual, void* y,
-                    mivp_stream_t stream);
+                    void* workspace, size_t ws_bytes, mivp_stream_t stream);
+/* bytes of f32 split-K workspace the call above wants for this shape (0 = none).  Few voxels with a very
+ * long K (bottleneck, first decoder stages) cannot fill 256 CUs by voxel tiles alone: K is cut into slices
+ * that write f32 partials, summed in a fixed order by an epilogue kernel.  Passing NULL runs unsplit. */
+size_t mivp_conv3d_fwd_ws(const MivpConvDesc* d);
 /* weight + bias gradient for small Cout (segmentation heads, Cout <= 8):
  *   dwdb [Cout*27*Cin + Cout] f32 : dw[co][tap][ci] = sum_v dy[v][co] * x'[v+tap][ci] followed by db[co]
  *   (x' = the operand the forward conv saw, i.e. after the fused scale/shift/activation);

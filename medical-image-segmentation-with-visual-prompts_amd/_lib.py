@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -54,6 +54,7 @@ def lib():
         _lib.mivp_last_error.restype = C.c_char_p
         _lib.mivp_conv3d_wgrad_small_ws.restype = C.c_size_t
         _lib.mivp_conv3d_wgrad_rows_ws.restype = C.c_size_t
+        _lib.mivp_conv3d_fwd_ws.restype = C.c_size_t
         ver = _lib.mivp_abi_version()
         if ver != ABI_VERSION:
             raise RuntimeError(f"mivp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")

@@ -70,8 +70,10 @@ def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout
     if wp.shape != (round_up(cout, 16), d.Kp):
         raise RuntimeError(f"conv3d: packed weight shape {tuple(wp.shape)} does not match Cout={cout}, Cin={cin}")
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     L.call("mivp_conv3d_fwd", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(scale), L.ptr(shift),
-           L.ptr(residual), L.ptr(y), L.stream())
+           L.ptr(residual), L.ptr(y), L.ptr(ws), C.c_size_t(ws_bytes), L.stream())
     return y
 
 
