@@ -266,6 +266,18 @@ int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void
 int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip, mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* Dice + focal loss of the downstream step (modules/segmentation.py:44-50)  */
+/* ------------------------------------------------------------------------ */
+/* logits f32 [B, vol, C] channels-last (C <= 8), target f32 [B, vol] class indices.
+ * loss[0] = mean_bc dice_bc + mean focal (MONAI DiceFocalLoss(include_background, to_onehot_y, softmax,
+ * gamma) as documented; class 0 dropped when include_background == 0); dlogits f32 [B, vol, C] = d loss / d logits.
+ * workspace: mivp_dice_focal_ws(B, vol) floats.                                                    */
+size_t mivp_dice_focal_ws(int32_t B, int64_t vol);
+int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
+                    int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
+                    mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* small utilities                                                          */
 /* ------------------------------------------------------------------------ */
 /* fp32 -> bf16 cast of n elements (weight staging) */

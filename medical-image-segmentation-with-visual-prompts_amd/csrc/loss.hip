@@ -1,0 +1,171 @@
+// Dice + (sigmoid) focal loss of the downstream step, forward value and gradient in two streaming passes
+// over the logits.  Reference: modules/segmentation.py:44-50 constructs MONAI
+// DiceFocalLoss(include_background, to_onehot_y=True, softmax=True, gamma=4.0); the formula is restated
+// from MONAI's documentation (MONAI is absent from the image: parity unpinned, see oracle/loss_ref.py).
+//   dice_bc = 1 - (2 I_bc + e) / (P_bc + T_bc + e),  I = sum p*t, P = sum p, T = sum t,  p = softmax_c(z)
+//   focal   = mean over (b, c, voxel) of  exp(gamma * logsig(-z*(2t-1))) * (z - z*t - logsig(z))
+//   loss    = mean_bc dice_bc + focal          (class 0 dropped from both when include_background == 0)
+#include "common.hpp"
+
+namespace {
+constexpr int LOSS_MAXC = 8;
+MIVP_DEV float log_sigmoid(float u) { return fminf(u, 0.f) - log1pf(__expf(-fabsf(u))); }
+MIVP_DEV float sigmoid(float u) { return 1.f / (1.f + __expf(-u)); }
+}
+
+// pass 1: per-block partial sums  [3*C (I, P, T per class) + 1 (focal sum)]  for ONE batch element per block row
+__global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restrict__ z, const float* __restrict__ y, long vol,
+                                                          int C, int c0, float gamma, int blocks_per_b,
+                                                          float* __restrict__ part) {
+    __shared__ float red[4][3 * LOSS_MAXC + 1];
+    const int b = blockIdx.x / blocks_per_b, blk = blockIdx.x % blocks_per_b;
+    float acc[3 * LOSS_MAXC + 1];
+#pragma unroll
+    for (int i = 0; i < 3 * LOSS_MAXC + 1; ++i) acc[i] = 0.f;
+    for (long v = (long)blk * 256 + threadIdx.x; v < vol; v += (long)blocks_per_b * 256) {
+        const float* zv = z + ((long)b * vol + v) * C;
+        const int cls = (int)y[(long)b * vol + v];
+        float zz[LOSS_MAXC], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { zz[c] = zv[c]; mx = fmaxf(mx, zz[c]); }
+        float den = 0.f, e[LOSS_MAXC];
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { e[c] = __expf(zz[c] - mx); den += e[c]; }
+        const float inv_den = 1.f / den;
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) {
+            if (c < C && c >= c0) {
+                const float p = e[c] * inv_den, t = (c == cls) ? 1.f : 0.f;
+                acc[3 * c] += p * t;
+                acc[3 * c + 1] += p;
+                acc[3 * c + 2] += t;
+                const float bce = zz[c] - zz[c] * t - log_sigmoid(zz[c]);
+                acc[3 * LOSS_MAXC] += __expf(gamma * log_sigmoid(-zz[c] * (2.f * t - 1.f))) * bce;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3 * LOSS_MAXC + 1; ++i) {
+        float vsum = acc[i];
+        for (int o = 32; o > 0; o >>= 1) vsum += __shfl_xor(vsum, o);
+        if (lane == 0) red[wave][i] = vsum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * LOSS_MAXC + 1) {
+        const int i = threadIdx.x;
+        part[(long)blockIdx.x * (3 * LOSS_MAXC + 1) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
+// sums [B][blocks_per_b][25] -> stats [B][25] (fixed order), loss value
+__global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int blocks_per_b, long vol, int C, int c0,
+                                      float* __restrict__ stats, float* __restrict__ loss) {
+    __shared__ float dice_sum, focal_sum;
+    const int K = 3 * LOSS_MAXC + 1;
+    if (threadIdx.x == 0) { dice_sum = 0.f; focal_sum = 0.f; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * K; i += blockDim.x) {
+        const int b = i / K, k = i - b * K;
+        double s = 0.0;
+        for (int j = 0; j < blocks_per_b; ++j) s += (double)part[((long)b * blocks_per_b + j) * K + k];
+        stats[i] = (float)s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float d = 0.f, f = 0.f;
+        for (int b = 0; b < B; ++b) {
+            for (int c = c0; c < C; ++c) {
+                const float I = stats[b * K + 3 * c], P = stats[b * K + 3 * c + 1], T = stats[b * K + 3 * c + 2];
+                d += 1.f - (2.f * I + 1e-5f) / (P + T + 1e-5f);
+            }
+            f += stats[b * K + 3 * LOSS_MAXC];
+        }
+        const float ncls = (float)(C - c0);
+        loss[0] = d / ((float)B * ncls) + f / ((float)B * ncls * (float)vol);
+    }
+}
+
+// pass 2: dz = dL/dz  (f32, same layout as z)
+__global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict__ z, const float* __restrict__ y, long vol,
+                                                         int B, int C, int c0, float gamma, const float* __restrict__ stats,
+                                                         float* __restrict__ dz) {
+    const int K = 3 * LOSS_MAXC + 1;
+    const long total = (long)B * vol;
+    const float ncls = (float)(C - c0);
+    const float wd = 1.f / ((float)B * ncls), wf = 1.f / ((float)B * ncls * (float)vol);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / vol);
+        const float* zv = z + i * C;
+        const int cls = (int)y[i];
+        float zz[LOSS_MAXC], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { zz[c] = zv[c]; mx = fmaxf(mx, zz[c]); }
+        float den = 0.f, p[LOSS_MAXC];
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { p[c] = __expf(zz[c] - mx); den += p[c]; }
+        const float inv_den = 1.f / den;
+        float q[LOSS_MAXC], pq = 0.f;
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) {
+            if (c < C) {
+                p[c] *= inv_den;
+                float qc = 0.f;
+                if (c >= c0) {
+                    const float I = stats[b * K + 3 * c], P = stats[b * K + 3 * c + 1], T = stats[b * K + 3 * c + 2];
+                    const float Dn = P + T + 1e-5f, Nn = 2.f * I + 1e-5f;
+                    qc = wd * (Nn / (Dn * Dn) - ((c == cls) ? 2.f / Dn : 0.f));     // d(dice mean)/dp_c
+                }
+                q[c] = qc;
+                pq += p[c] * qc;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < LOSS_MAXC; ++c) {
+            if (c < C) {
+                float gz = p[c] * (q[c] - pq);                                        // through the softmax
+                if (c >= c0) {
+                    const float t = (c == cls) ? 1.f : 0.f, s = 2.f * t - 1.f;
+                    const float w = __expf(gamma * log_sigmoid(-zz[c] * s));
+                    const float bce = zz[c] - zz[c] * t - log_sigmoid(zz[c]);
+                    gz += wf * (w * (sigmoid(zz[c]) - t) - bce * gamma * w * s * sigmoid(zz[c] * s));
+                }
+                dz[i * C + c] = gz;
+            }
+        }
+    }
+}
+
+extern "C" size_t mivp_dice_focal_ws(int32_t B, int64_t vol) {
+    long bpb = (vol + 256 * 16 - 1) / (256 * 16);
+    if (bpb > 256) bpb = 256;
+    if (bpb < 1) bpb = 1;
+    return (size_t)B * (bpb + 1) * (3 * LOSS_MAXC + 1);
+}
+
+extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
+                               int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
+                               mivp_stream_t stream) {
+    MIVP_REQUIRE(logits && target && workspace && loss && dlogits);
+    MIVP_REQUIRE(B > 0 && vol > 0 && C >= 2 && C <= LOSS_MAXC);
+    const int K = 3 * LOSS_MAXC + 1;
+    long bpb = (vol + 256 * 16 - 1) / (256 * 16);
+    if (bpb > 256) bpb = 256;
+    if (bpb < 1) bpb = 1;
+    const int c0 = include_background ? 0 : 1;
+    float* part = workspace;
+    float* stats = workspace + (long)B * bpb * K;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dice_focal_stats, dim3((unsigned)(B * bpb)), dim3(256), 0, st, logits, target, (long)vol, (int)C, c0,
+                       gamma, (int)bpb, part);
+    int rc = mivp_check_launch("dice_focal_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(256), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
+    rc = mivp_check_launch("dice_focal_finalize");
+    if (rc) return rc;
+    const long total = (long)B * vol;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_dice_focal_grad, dim3(grid), dim3(256), 0, st, logits, target, (long)vol, (int)B, (int)C, c0, gamma,
+                       stats, dlogits);
+    return mivp_check_launch("dice_focal_grad");
+}

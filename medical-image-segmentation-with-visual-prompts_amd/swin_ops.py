@@ -36,6 +36,7 @@ class SwinBlockWeights:
     wqkv_t: Optional[torch.Tensor] = None    # bf16 [C, 3C]   (backward)
     wproj_t: Optional[torch.Tensor] = None   # bf16 [C, C]
     wmlp_t: Optional[torch.Tensor] = None
+    aug_cache: Optional[dict] = None         # (Nqp, Nkp, augp) -> (qa, ka) for prompt-free calls (constants of the weights)
 
 
 def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=False) -> SwinBlockWeights:
@@ -126,9 +127,18 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
         pr = prompt.detach().to(torch.float32).contiguous()
         L.call("mivp_prompt_kv_fwd", C.byref(d), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
                L.ptr(kp), L.ptr(vp), L.ptr(None), st)
-    qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
-    ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
-    L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(ts), L.ptr(qa), L.ptr(ka), st)
+    aug_key = (d.Nqp, d.Nkp, d.augp)
+    cached = None if (n_prompt or w.aug_cache is None) else w.aug_cache.get(aug_key)
+    if cached is not None:
+        qa, ka = cached
+    else:
+        qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
+        ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
+        L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(ts), L.ptr(qa), L.ptr(ka), st)
+        if not n_prompt:                     # without prompt columns the tables depend on the (frozen) weights only
+            if w.aug_cache is None:
+                w.aug_cache = {}
+            w.aug_cache[aug_key] = (qa, ka)
     o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
     lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
     L.call("mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp), L.ptr(qa), L.ptr(ka),

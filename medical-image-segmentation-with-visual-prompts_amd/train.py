@@ -56,11 +56,41 @@ def synthetic_batch(conf: Namespace, batch: int, size: int, device, rank: int = 
     return x.to(device), y.to(device)
 
 
+class _DiceFocalFn(torch.autograd.Function):
+    """Loss value and d loss / d logits from two streaming HIP passes (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits_cl, target, include_background, gamma):
+        import ctypes as C
+        from . import _lib as L
+        B, H, W, D, Cc = logits_cl.shape
+        vol = H * W * D
+        ws = torch.empty(L.lib().mivp_dice_focal_ws(C.c_int32(B), C.c_int64(vol)), dtype=torch.float32, device=logits_cl.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits_cl.device)
+        dz = torch.empty_like(logits_cl)
+        L.call("mivp_dice_focal", L.ptr(logits_cl), L.ptr(target), C.c_int32(B), C.c_int64(vol), C.c_int32(Cc),
+               C.c_int32(1 if include_background else 0), C.c_float(gamma), L.ptr(ws), L.ptr(loss), L.ptr(dz), L.stream())
+        ctx.save_for_backward(dz)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None, None
+
+
 def dice_focal_loss(logits: torch.Tensor, target: torch.Tensor, include_background: bool = True,
                     gamma: float = 4.0) -> torch.Tensor:
     """MONAI ``DiceFocalLoss(include_background, to_onehot_y=True, softmax=True, gamma=4)`` as documented
     (segmentation.py:44-50): Dice on softmax probabilities (smooth 1e-5) + sigmoid focal loss, both
-    averaged.  logits [B,C,H,W,D] float, target [B,1,H,W,D] float class indices."""
+    averaged.  logits [B,C,H,W,D] float, target [B,1,H,W,D] float class indices.
+
+    When the logits are the channels-first VIEW the HIP model returns (fp32, channels-last storage) the loss
+    and its gradient come from the fused HIP kernel; any other layout takes the plain PyTorch formula."""
+    base = logits.permute(0, 2, 3, 4, 1)
+    if logits.is_cuda and logits.dtype == torch.float32 and base.is_contiguous() and logits.shape[1] <= 8 \
+            and target.is_contiguous() and target.dtype == torch.float32:
+        return _DiceFocalFn.apply(base, target, include_background, gamma)
     C = logits.shape[1]
     onehot = F.one_hot(target[:, 0].long(), C).permute(0, 4, 1, 2, 3).to(logits.dtype)
     prob = logits.softmax(dim=1)

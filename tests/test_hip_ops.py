@@ -219,3 +219,21 @@ def test_head_backward_from_one_mfma_pass(cin, cout, dims, training):
         pass
     assert rel_l2(dgamma.cpu(), gamma.grad) < 5e-3
     assert rel_l2(dbeta.cpu(), beta.grad) < 5e-3
+
+
+@pytest.mark.parametrize("C,inc_bg", [(2, True), (2, False), (5, True)])
+def test_dice_focal_loss_value_and_gradient(C, inc_bg):
+    """fused HIP loss vs the oracle's restatement of MONAI DiceFocalLoss (parity unpinned: MONAI absent)."""
+    from mivp_amd import train
+    from oracle.loss_ref import dice_focal_loss as oracle_loss
+    g = torch.Generator().manual_seed(C)
+    logits = (2.0 * torch.randn(2, C, 6, 7, 8, generator=g)).requires_grad_(True)
+    y = torch.randint(0, C, (2, 1, 6, 7, 8), generator=g).float()
+    want = oracle_loss(logits, y, inc_bg, 4.0)
+    want.backward()
+    base = logits.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    got = train.dice_focal_loss(base.permute(0, 4, 1, 2, 3), y.to(DEV), inc_bg, 4.0)
+    (got * 1.0).backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(want)) < 2e-5 * max(1.0, abs(float(want)))
+    assert rel_l2(base.grad.cpu().permute(0, 4, 1, 2, 3), logits.grad) < 1e-4
