@@ -192,6 +192,14 @@ int mivp_conv3d_fwd(const MivpConvDesc* d, const void* x, const void* w, const f
  * long K (bottleneck, first decoder stages) cannot fill 256 CUs by voxel tiles alone: K is cut into slices
  * that write f32 partials, summed in a fixed order by an epilogue kernel.  Passing NULL runs unsplit. */
 size_t mivp_conv3d_fwd_ws(const MivpConvDesc* d);
+/* Segmentation-head forward (swin_unetr.py:229-237): y = conv3x3x3(x * scale + shift) + bias for 27*Cout <= 64
+ * (Cout <= 2), Cin + 1 <= 64.  x [B,H,W,D,Cin] bf16 (pre-BatchNorm), w f32 [Cout][Cin][3][3][3] (the nn.Conv3d
+ * weight as stored), scale/shift f32 [Cin] (BatchNorm as an affine), y f32 [B,H,W,D,Cout].
+ * Per-voxel GEMM to the 27*Cout tap outputs on MFMA + 27-point gather through LDS (csrc/head.hip). */
+size_t mivp_head_conv_ws(void);            /* bytes of workspace (the folded bf16 weight tile) */
+int mivp_head_conv_fwd(const MivpConvDesc* d, const void* x, const float* w, const float* bias,
+                       const float* scale, const float* shift, void* workspace, float* y, mivp_stream_t stream);
+
 /* weight + bias gradient for small Cout (segmentation heads, Cout <= 8):
  *   dwdb [Cout*27*Cin + Cout] f32 : dw[co][tap][ci] = sum_v dy[v][co] * x'[v+tap][ci] followed by db[co]
  *   (x' = the operand the forward conv saw, i.e. after the fused scale/shift/activation);

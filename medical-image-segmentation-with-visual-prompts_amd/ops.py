@@ -77,6 +77,22 @@ def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout
     return y
 
 
+def head_conv_supported(cin: int, cout: int) -> bool:
+    return 27 * cout <= 60 and cin + 1 <= 64 and cin % 8 == 0
+
+
+def head_conv(x, conv_w, conv_b, scale, shift):
+    """Segmentation head: conv3x3x3(BatchNorm-affine(x)) + bias -> f32 logits, one fused kernel."""
+    B, H, W, D, cin = x.shape
+    cout = conv_w.shape[0]
+    d = conv_desc(B, (H, W, D), cin, cout, True, False, False, True)
+    y = torch.empty((B, H, W, D, cout), dtype=torch.float32, device=x.device)
+    ws = torch.empty(64 * 64, dtype=BF16, device=x.device)
+    L.call("mivp_head_conv_fwd", C.byref(d), L.ptr(x), L.ptr(conv_w.detach().float().contiguous()),
+           L.ptr(conv_b.detach().float().contiguous()), L.ptr(scale), L.ptr(shift), L.ptr(ws), L.ptr(y), L.stream())
+    return y
+
+
 def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
     """dw [Cout,Cin,3,3,3] f32 and db [Cout] f32 for a small-Cout conv (segmentation heads)."""
     B, H, W, D, cin = x.shape

@@ -237,3 +237,18 @@ def test_dice_focal_loss_value_and_gradient(C, inc_bg):
     torch.cuda.synchronize()
     assert abs(float(got) - float(want)) < 2e-5 * max(1.0, abs(float(want)))
     assert rel_l2(base.grad.cpu().permute(0, 4, 1, 2, 3), logits.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,dims", [(48, 2, (8, 8, 16)), (48, 2, (9, 6, 21)), (8, 2, (4, 5, 7)), (32, 1, (6, 6, 6))])
+def test_head_conv_fused(cin, cout, dims):
+    """BatchNorm-affine + 3x3x3 conv to <= 2 channels through the per-voxel-GEMM + gather kernel."""
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + dims[2])
+    x = r16(torch.randn(2, cin, *dims, generator=g))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = 0.1 * torch.randn(cout, generator=g)
+    scale, shift = 1 + 0.2 * torch.randn(cin, generator=g), 0.2 * torch.randn(cin, generator=g)
+    want = F.conv3d(x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), w, b, padding=1)
+    y = ops.head_conv(cl(x), w.to(DEV), b.to(DEV), scale.to(DEV), shift.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want) < 3e-3       # bf16 weights (scale folded in) and fp16 tap partials

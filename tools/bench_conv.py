@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, ".")
 import mivp_amd
 from mivp_amd import ops
-SH = {"dec2": (144, 48, (48, 48, 48), True), "dec1": (288, 96, (24, 24, 24), True), "dec0": (576, 192, (12, 12, 24), True),
+SH = {"headf": (48, 2, (96, 96, 96), True), "dec2": (144, 48, (48, 48, 48), True), "dec1": (288, 96, (24, 24, 24), True), "dec0": (576, 192, (12, 12, 24), True),
       "bott": (384, 384, (6, 6, 24), False), "head": (48, 2, (96, 96, 96), True)}
 name = sys.argv[1] if len(sys.argv) > 1 else "dec2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -21,7 +21,10 @@ shift = None
 for it in range(iters + 2):
     if it == 2:
         torch.cuda.synchronize(); t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
-    y = ops.conv3d(x, wp, b, cout, scale, shift, aff and name != "head", None, name == "head")
+    if name == "headf":
+        y = ops.head_conv(x, w, b, torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
+    else:
+        y = ops.conv3d(x, wp, b, cout, scale, shift, aff and name != "head", None, name == "head")
 t1.record(); torch.cuda.synchronize()
 ms = t0.elapsed_time(t1) / iters
 fl = 2.0 * 27 * cin * cout * 4 * dims[0] * dims[1] * dims[2]
