@@ -61,6 +61,20 @@ MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live) {
     return excl ? -INFINITY : v;
 }
 
+// LDS image of 16-byte-chunked operand rows read as MFMA fragments (lane = (row r, chunk g), ds_read_b128).
+// DK == 32: rows are exactly 64 bytes and the chunk index is XOR-swizzled with {0,3,2,1}[(row >> 2) & 3], which
+// makes every 16-lane service group of ds_read_b128 cover all sixteen 16-byte slots of the 256-byte bank row
+// (no bank conflicts, no padding; same swizzle as the conv kernel).  Wider rows keep a +16-byte pad.
+template <int DK>
+struct OperandRows {
+    static constexpr int ROW = DK == 32 ? 64 : (DK + 8) * 2;                       // bytes per row
+    // byte offset of element `elem` (a multiple of 4) of row `row`
+    static MIVP_DEV int off(int row, int elem) {
+        if (DK == 32) return row * 64 + 16 * ((elem >> 3) ^ ((0 - (row >> 2)) & 3)) + 2 * (elem & 7);
+        return row * ROW + 2 * elem;
+    }
+};
+
 // error plumbing shared by the C-ABI translation units
 void mivp_set_error(const char* msg);
 int mivp_check_launch(const char* what);

@@ -175,7 +175,8 @@ struct AttnBwdGeom {
     static constexpr bool V16 = (DVT == 1);                 // head_dim <= 16: 16-wide value rows + K=16 MFMA
     static constexpr int DVS = (DVT + 1) / 2;
     static constexpr int DVP = V16 ? 16 : 32 * DVS;
-    static constexpr int KROW = (DK + 8) * 2;               // bytes per K'/Q' row
+    using KR = OperandRows<DK>;
+    static constexpr int KROW = KR::ROW;                     // bytes per K'/Q' row
     static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
 };
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
             } else if (c4 < hd4 + a4) {
                 val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
             }
-            *reinterpret_cast<bf16x4*>(Kimg + (size_t)lrow * KROW + 8 * c4) = val;
+            *reinterpret_cast<bf16x4*>(Kimg + G::KR::off(lrow, 4 * c4)) = val;
         }
         // K^T rows between hd and 16*DVT must be zero (they multiply dS in the dq MFMA)
         for (int e = tid; e < (16 * DVT - hd) * nkeys; e += 64 * NW) {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                     f32x4 s = fzero4(), dp = fzero4();
 #pragma unroll
                     for (int ks = 0; ks < DKS; ++ks)
-                        s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * lt + r) * KROW + (32 * ks + 8 * g) * 2), qf[ks], s);
+                        s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), qf[ks], s);
                     if (G::V16) {
                         dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Vimg + (size_t)(16 * lt + r) * VROWB + 8 * g), dof4, dp);
                     } else {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<bf16_t*>(Qt + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = (c4 < hd4) ? val[i] : (bf16_t)0.0f;
             }
-            *reinterpret_cast<bf16x4*>(Qimg + (size_t)lrow * QROW + 8 * c4) = val;
+            *reinterpret_cast<bf16x4*>(Qimg + G::KR::off(lrow, 4 * c4)) = val;
         }
         for (int e = tid; e < nq * dvp4; e += 64 * NW) {
             const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
                     f32x4 s = fzero4(), dp = fzero4();
 #pragma unroll
                     for (int ks = 0; ks < DKS; ++ks)
-                        s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + (size_t)(16 * lt + r) * QROW + (32 * ks + 8 * g) * 2), kf[ks], s);
+                        s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), kf[ks], s);
                     if (G::V16) {
                         dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Oimg + (size_t)(16 * lt + r) * OROW + 8 * g), vf4, dp);
                     } else {

@@ -8,7 +8,9 @@
 //   one wave = 32 tokens (two 16-token B tiles) so that every weight fragment fetched from L2
 //   feeds two MFMAs; no LDS: the B operand (tokens) is loaded straight into its MFMA lane map
 //   (lane r,g holds 8 consecutive channels of token r), LayerNorm statistics are per-lane
-//   partials + two xor-shuffles.
+//   partials + two xor-shuffles.  gridDim.y splits the 3C output columns: the deep stages have
+//   only ~22k tokens (700 waves for 1024 SIMDs), so several waves share a token tile and each
+//   takes a slice of the output tiles (the LayerNorm is recomputed per slice, it is cheap).
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16_t* __restrict__ x,
@@ -75,7 +77,10 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
 
     const int n_out = 3 * C;
     const int n_tiles = (n_out + 15) / 16;
-    for (int nt = 0; nt < n_tiles; ++nt) {
+    const int per_split = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const int nt_begin = blockIdx.y * per_split;
+    const int nt_end = nt_begin + per_split < n_tiles ? nt_begin + per_split : n_tiles;
+    for (int nt = nt_begin; nt < nt_end; ++nt) {
         f32x4 acc0 = fzero4(), acc1 = fzero4();
         const int nrow = 16 * nt + r;
 #pragma unroll
@@ -214,7 +219,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                                                          float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DK = 32 * DKS;
-    constexpr int KROW = (DK + 8) * 2;                       // bytes
+    using KR = OperandRows<DK>;
+    constexpr int KROW = KR::ROW;                            // bytes
     const int Nkp = d.Nkp, Nqp = d.Nqp;
     const int VROW = (Nkp + 8) * 2;                          // bytes
     char* Kimg = smem;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
         } else if (c4 < hd4 + a4) {
             val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
         }
-        *reinterpret_cast<bf16x4*>(Kimg + (size_t)row * KROW + 8 * c4) = val;
+        *reinterpret_cast<bf16x4*>(Kimg + KR::off(row, 4 * c4)) = val;
     }
     // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows) ----
     for (int e = tid; e < Nkp * (4 * DVT); e += 64 * NW) {
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                 f32x4 acc = fzero4();
 #pragma unroll
                 for (int s = 0; s < DKS; ++s)
-                    acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + (size_t)(16 * t + r) * KROW + (32 * s + 8 * g) * 2), qf[s], acc);
+                    acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * t + r, 32 * s + 8 * g)), qf[s], acc);
                 if (t < nt_full) {
                     if (d.has_mask) {
                         const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
@@ -486,10 +492,16 @@ extern "C" int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int
     if (rc) return rc;
     MIVP_REQUIRE(x && tok_src && ln_w && ln_b && wqkv && q && k && v);
     const long T = (long)d->B * d->P * d->Nqp;
-    const unsigned grid = (unsigned)((T + 127) / 128);
+    const unsigned gx = (unsigned)((T + 127) / 128);
     const int KS = (d->C + 31) / 32;
+    // enough waves for ~4 per SIMD: split the output columns when the token count alone cannot provide them
+    const int n_tiles = (3 * d->C + 15) / 16;
+    int nsplit = (int)((4096 + 4L * gx - 1) / (4L * gx));
+    if (nsplit > n_tiles / 3) nsplit = n_tiles / 3;
+    if (nsplit < 1) nsplit = 1;
+    const dim3 grid(gx, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_QKV(K) hipLaunchKernelGGL((k_swin_qkv_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)x, tok_src, \
+#define LAUNCH_QKV(K) hipLaunchKernelGGL((k_swin_qkv_fwd<K>), grid, dim3(256), 0, st, *d, (const bf16_t*)x, tok_src, \
                                           ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v)
     switch (KS) {
         case 1: LAUNCH_QKV(1); break;
@@ -529,7 +541,7 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
                            const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
                            hipStream_t st) {
     constexpr int NW = 8;
-    const size_t krow = (32 * DKS + 8) * 2, vrow = (d->Nkp + 8) * 2;
+    const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     auto kern = k_win_attn_fwd<DKS, DVT, NW>;
