@@ -50,6 +50,17 @@ def conv_flops(desc):
     return 2.0 * 27 * desc.Cin * desc.Cout * vox
 
 
+def traffic_bytes():
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_traffic.json:
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["conv3d_dec2"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -75,8 +86,9 @@ def cpu_baseline(conf, size):
         sd[k].requires_grad_(True)
     opt = torch.optim.AdamW([sd[k] for k in keys], lr=1e-3, weight_decay=0.0)
     g = torch.Generator().manual_seed(1234)
-    x = torch.rand(1, conf.input_channels, size, size, size, generator=g)
-    y = torch.randint(0, conf.output_channels_downstream, (1, 1, size, size, size), generator=g).float()
+    nvol = 4 if not (conf.use_encoder_prompting or conf.use_decoder_prompting) else 1     # ~10-30 s of CPU work
+    x = torch.rand(nvol, conf.input_channels, size, size, size, generator=g)
+    y = torch.randint(0, conf.output_channels_downstream, (nvol, 1, size, size, size), generator=g).float()
     t0 = time.perf_counter()
     out, _ = model(x, training=True)
     loss = dice_focal_loss(out["downstream"], y, conf.include_background)
@@ -84,8 +96,8 @@ def cpu_baseline(conf, size):
     loss.backward()
     opt.step()
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step on 1 volume of {size}^3 (fp32 PyTorch oracle, {dt:.1f} s)"}
+    return {"value": nvol / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step on a batch of {nvol} volume(s) of {size}^3 (fp32 PyTorch oracle, {dt:.1f} s)"}
 
 
 def main():
@@ -114,8 +126,7 @@ def main():
     # dominant kernel: the last decoder stage's conv_concat (implicit GEMM, K = 27*144, N = 48)
     hc = conf.hidden_channels
     dom_cin, dom_cout = hc[0] + hc[1], hc[0]
-    _lib.profile_select("mivp_conv3d_fwd", lambda a: a[0]._obj.Cin == dom_cin and a[0]._obj.Cout == dom_cout
-                        and a[0]._obj.pro_affine == 1)
+    _lib.profile_select("mivp_conv3d_fwd", lambda a: a[0]._obj.Cin == dom_cin and a[0]._obj.Cout == dom_cout)
 
     def sync():
         train.barrier_sync(dev)
@@ -140,9 +151,9 @@ def main():
         if kern_n:
             fl = conv_flops(kern_desc)
             achieved = fl / (kern_ms * 1e-3) / 1e12
-            roof = {"kernel": "k_conv3d_fwd<3> (decoder stage 2 conv_concat: BN+LeakyReLU prologue, 144->48, 48^3)",
+            roof = {"kernel": "k_conv3d_fwd<3,8,2> (decoder stage 2 conv_concat: 3x3x3 implicit GEMM, 144->48 channels, 48^3 voxels)",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic_bytes(),
                     "launches_timed": kern_n, "avg_launch_ms": kern_ms, "flops_per_launch": fl}
         line = {
             "metric": "3D volumes/sec (96^3, bf16) training step", "value": world * batch * args.steps / dt,
