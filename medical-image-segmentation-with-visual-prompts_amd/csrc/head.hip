@@ -22,19 +22,21 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // A operand, built once per call: row (tap, co) = tap*Cout + co ; column k < Cin: scale[k] * w[co][k][tap] ;
 // column k == Cin: sum_c shift[c] * w[co][c][tap] (multiplies the "ones" channel) ; bf16 [64][64]
-__global__ __launch_bounds__(256) void k_head_pack(MivpConvDesc d, const float* __restrict__ w, const float* __restrict__ scale,
-                                                   const float* __restrict__ shift, bf16_t* __restrict__ apack) {
+__global__ __launch_bounds__(64) void k_head_pack(MivpConvDesc d, const float* __restrict__ w, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, bf16_t* __restrict__ apack) {
+    // one 64-lane block per row (tap, co); lane = column k
     const int Cin = d.Cin, Cout = d.Cout, rows = 27 * Cout;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int row = e >> 6, k = e & 63;
-        float val = 0.f;
-        if (row < rows) {
-            const int tap = row / Cout, co = row - tap * Cout;
-            if (k < Cin) val = scale[k] * w[((long)co * Cin + k) * 27 + tap];
-            else if (k == Cin) { for (int c = 0; c < Cin; ++c) val += shift[c] * w[((long)co * Cin + c) * 27 + tap]; }
-        }
-        apack[e] = (bf16_t)val;
+    const int row = blockIdx.x, k = threadIdx.x;
+    float val = 0.f;
+    if (row < rows) {
+        const int tap = row / Cout, co = row - tap * Cout;
+        float part = 0.f;
+        for (int c = k; c < Cin; c += 64) part += shift[c] * w[((long)co * Cin + c) * 27 + tap];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (k < Cin) val = scale[k] * w[((long)co * Cin + k) * 27 + tap];
+        else if (k == Cin) val = part;
     }
+    apack[row * 64 + k] = (bf16_t)val;
 }
 
 template <int KS>     // K steps of 32 covering Cin + 1 (the ones channel)
@@ -134,7 +136,7 @@ extern "C" int mivp_head_conv_fwd(const MivpConvDesc* d, const void* x, const fl
     const long nb = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + HB_W - 1) / HB_W) * ((d->dims[2] + HB_D - 1) / HB_D);
     const size_t lds = (size_t)HTILES * 16 * YROW;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_pack, dim3(1), dim3(256), 0, st, *d, w, scale, shift, (bf16_t*)workspace);
+    hipLaunchKernelGGL(k_head_pack, dim3(64), dim3(64), 0, st, *d, w, scale, shift, (bf16_t*)workspace);
     int rc = mivp_check_launch("head_pack");
     if (rc) return rc;
     if (ks == 1) {

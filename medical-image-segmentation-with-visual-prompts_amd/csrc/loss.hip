@@ -65,11 +65,14 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
     const int K = 3 * LOSS_MAXC + 1;
     if (threadIdx.x == 0) { dice_sum = 0.f; focal_sum = 0.f; }
     __syncthreads();
-    for (int i = threadIdx.x; i < B * K; i += blockDim.x) {
+    // one wave per (b, k) sum: lanes stride over the per-block partials, then a butterfly (fixed order)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int i = wv; i < B * K; i += nwv) {
         const int b = i / K, k = i - b * K;
         double s = 0.0;
-        for (int j = 0; j < blocks_per_b; ++j) s += (double)part[((long)b * blocks_per_b + j) * K + k];
-        stats[i] = (float)s;
+        for (int j = lane; j < blocks_per_b; j += 64) s += (double)part[((long)b * blocks_per_b + j) * K + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) stats[i] = (float)s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

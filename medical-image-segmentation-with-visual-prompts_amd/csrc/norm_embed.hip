@@ -4,6 +4,25 @@
 // accesses, per-thread fp32 partials, LDS atomics per workgroup, deterministic final reduction.
 #include "common.hpp"
 
+// Deterministic block reduction of per-thread channel-group partials: thread t (global id gt) owns channel group
+// gt % G; its 16 partial sums (8 channels x {s1, s2}) go to LDS and one thread per output channel adds the owners
+// of that group in a fixed order.  (LDS float atomics would be shorter but their order changes run to run, and the
+// BatchNorm statistics feed everything downstream.)  smem: 256 * 16 floats.
+MIVP_DEV void block_reduce_groups(float* lds, const float (&s1)[8], const float (&s2)[8], int G, int C, long block_first_gtid,
+                                  float* __restrict__ out2c) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { lds[tid * 16 + i] = s1[i]; lds[tid * 16 + 8 + i] = s2[i]; }
+    __syncthreads();
+    for (int o = tid; o < 2 * C; o += 256) {
+        const int which = o / C, c = o - which * C, cg = c >> 3, i = c & 7;
+        int t0 = (int)(((long)cg - block_first_gtid % G + G) % G);      // first thread of this block that owns group cg
+        float acc = 0.f;
+        for (int t = t0; t < 256; t += G) acc += lds[t * 16 + which * 8 + i];
+        out2c[o] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // patch embedding: y[b,h,w,d,co] = bias[co] + sum_{ci,a,b,c} x[b,ci,2h+a,2w+b,2d+c] * w[co,ci,a,b,c]
 //   work item = (output voxel, group of 8 output channels); total threads is a multiple of C/8 so a
@@ -17,10 +36,9 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = d.C, Cin = d.Cin, G = C / 8;
     float* wl = reinterpret_cast<float*>(smem);               // [C][Cin*8]
-    float* lsum = wl + C * Cin * 8;                            // [2C]
+    float* lsum = wl + C * Cin * 8;                            // [256 * 16] reduction scratch
     const int tid = threadIdx.x;
     for (int i = tid; i < C * Cin * 8; i += 256) wl[i] = w[i];
-    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
     __syncthreads();
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2];
     const int oh = H / 2, ow = W / 2, od = D / 2;
@@ -68,12 +86,7 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
             st8(y + vox * C + cg * 8, o);
         }
     }
-    if (mode == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
-        __syncthreads();
-        for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
-    }
+    if (mode == 0) block_reduce_groups(lsum, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
 }
 
 extern "C" int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x, const float* w, const float* bias,
@@ -83,7 +96,7 @@ extern "C" int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x
     MIVP_REQUIRE(d->dims[0] % 2 == 0 && d->dims[1] % 2 == 0 && d->dims[2] % 2 == 0);
     MIVP_REQUIRE((d->nblk * 256) % (d->C / 8) == 0);
     MIVP_REQUIRE(mode == 0 ? part != nullptr : (y && scale && shift));
-    const size_t lds = ((size_t)d->C * d->Cin * 8 + 2 * d->C) * sizeof(float);
+    const size_t lds = ((size_t)d->C * d->Cin * 8 + 256 * 16) * sizeof(float);
     hipLaunchKernelGGL(k_patch_embed, dim3(d->nblk), dim3(256), lds, (hipStream_t)stream, *d, mode, x, w, bias, scale,
                        shift, part, (bf16_t*)y);
     return mivp_check_launch("patch_embed");
@@ -97,12 +110,9 @@ __global__ __launch_bounds__(256) void k_bn_stats(const bf16_t* __restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lsum = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, G = C / 8;
-    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
-    __syncthreads();
     const long items = n_vox * G;
     const long gtid = (long)blockIdx.x * 256 + tid;
     const long stride = (long)gridDim.x * 256;
-    const int cg = (int)(gtid % G);
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -111,16 +121,13 @@ __global__ __launch_bounds__(256) void k_bn_stats(const bf16_t* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
-    __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
+    block_reduce_groups(lsum, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
 }
 
 extern "C" int mivp_bn_stats(const void* x, int64_t n_vox, int32_t C, int32_t nblk, float* part, mivp_stream_t stream) {
     MIVP_REQUIRE(x && part && n_vox > 0 && C % 8 == 0 && nblk > 0);
     MIVP_REQUIRE((nblk * 256) % (C / 8) == 0);
-    hipLaunchKernelGGL(k_bn_stats, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
+    hipLaunchKernelGGL(k_bn_stats, dim3(nblk), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
                        (long)n_vox, (int)C, part);
     return mivp_check_launch("bn_stats");
 }
@@ -220,8 +227,6 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const bf16_t* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lsum = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, G = C / 8;
-    for (int i = tid; i < 2 * C; i += 256) lsum[i] = 0.f;
-    __syncthreads();
     const long items = n_vox * G;
     const long gtid = (long)blockIdx.x * 256 + tid;
     const long stride = (long)gridDim.x * 256;
@@ -244,10 +249,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const bf16_t* __restrict__
             s2[i] += gz * (xf - mu[i]) * rs[i];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { atomicAdd(&lsum[cg * 8 + i], s1[i]); atomicAdd(&lsum[C + cg * 8 + i], s2[i]); }
-    __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) part[(long)blockIdx.x * 2 * C + i] = lsum[i];
+    block_reduce_groups(lsum, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
 }
 
 extern "C" int mivp_bn_bwd_stats(const void* x, const void* dy, int64_t n_vox, int32_t C, const float* scale,
@@ -255,7 +257,7 @@ extern "C" int mivp_bn_bwd_stats(const void* x, const void* dy, int64_t n_vox, i
                                  mivp_stream_t stream) {
     MIVP_REQUIRE(x && dy && scale && shift && mean_rstd && part && n_vox > 0 && C % 8 == 0 && nblk > 0);
     MIVP_REQUIRE((nblk * 256) % (C / 8) == 0);
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(nblk), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)dy, (long)n_vox, (int)C, scale, shift, mean_rstd, (int)lrelu, part);
     return mivp_check_launch("bn_bwd_stats");
 }
