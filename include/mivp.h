@@ -286,6 +286,37 @@ int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t
                     mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* weight gradients: out[M][N] (+)= alpha * sum_t A[t][m] * B[t][n]          */
+/* (the dW of every nn.Linear / nn.Conv3d on the path when autograd reaches */
+/*  it: `loss.backward()` in segmentation.py:104, students_teacher.py:176)   */
+/* ------------------------------------------------------------------------ */
+typedef struct MivpOperandDesc {   /* where element (t, c) of a bf16 token-major operand lives */
+    int32_t mode;       /* 0: t*ld + c                                                          */
+                        /* 1: head-split [T/rows][C/hd][rows][hd] (attention q/k/v gradients)   */
+                        /* 2: conv tap: column c = tap*cin + ci reads voxel t displaced by the  */
+                        /*    tap (kh-1, kw-1, kd-1), zero outside the volume                   */
+    int32_t ld;         /* mode 0/2: elements per row, multiple of 4                             */
+    int32_t rows, hd;   /* mode 1 (hd multiple of 4)                                            */
+    int32_t dims[3];    /* mode 2: H, W, D; t = ((b*H + h)*W + w)*D + d                          */
+    int32_t cin;        /* mode 2: channels per tap, multiple of 4                               */
+} MivpOperandDesc;
+
+typedef struct MivpGemmTnDesc {
+    int64_t T;          /* tokens / voxels summed over                                          */
+    int32_t M, N;       /* out is fp32 [M][N] row-major                                          */
+    MivpOperandDesc a;  /* supplies the M index (gradient w.r.t. the layer output)              */
+    MivpOperandDesc b;  /* supplies the N index (the layer input)                               */
+    float   alpha;
+    int32_t accumulate; /* 1: out += result                                                      */
+    int32_t perm_cin;   /* > 0 (== b.cin, mode 2): store column tap*cin + ci at ci*27 + tap,     */
+                        /* i.e. out is nn.Conv3d.weight's [Cout][Cin][3][3][3]                   */
+} MivpGemmTnDesc;
+
+size_t mivp_gemm_tn_ws(const MivpGemmTnDesc* d);   /* fp32 split partials */
+int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* b, void* workspace, size_t ws_bytes,
+                 float* out, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* small utilities                                                          */
 /* ------------------------------------------------------------------------ */
 /* fp32 -> bf16 cast of n elements (weight staging) */

@@ -39,6 +39,15 @@ class UpcatDesc(C.Structure):
     _fields_ = [("B", i32), ("idims", i32 * 3), ("odims", i32 * 3), ("scale", i32 * 3), ("Cx", i32), ("Cs", i32)]
 
 
+class OperandDesc(C.Structure):
+    _fields_ = [("mode", i32), ("ld", i32), ("rows", i32), ("hd", i32), ("dims", i32 * 3), ("cin", i32)]
+
+
+class GemmTnDesc(C.Structure):
+    _fields_ = [("T", i64), ("M", i32), ("N", i32), ("a", OperandDesc), ("b", OperandDesc), ("alpha", f32),
+                ("accumulate", i32), ("perm_cin", i32)]
+
+
 _lib = None
 
 
@@ -57,6 +66,7 @@ def lib():
         _lib.mivp_conv3d_fwd_ws.restype = C.c_size_t
         _lib.mivp_dice_focal_ws.restype = C.c_size_t
         _lib.mivp_head_conv_ws.restype = C.c_size_t
+        _lib.mivp_gemm_tn_ws.restype = C.c_size_t
         ver = _lib.mivp_abi_version()
         if ver != ABI_VERSION:
             raise RuntimeError(f"mivp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")

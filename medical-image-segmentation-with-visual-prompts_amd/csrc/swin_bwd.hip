@@ -912,6 +912,8 @@ extern "C" int mivp_sizeof_desc(int which) {
         case 2: return (int)sizeof(MivpConvDesc);
         case 3: return (int)sizeof(MivpEmbedDesc);
         case 4: return (int)sizeof(MivpUpcatDesc);
+        case 5: return (int)sizeof(MivpOperandDesc);
+        case 6: return (int)sizeof(MivpGemmTnDesc);
         default: return -1;
     }
 }

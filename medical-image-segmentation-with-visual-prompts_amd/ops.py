@@ -322,3 +322,35 @@ def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last):
     L.call("mivp_patch_merge_bwd", C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w_t_bf16), L.ptr(dx),
            L.stream())
     return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# weight gradients (csrc/wgrad.hip): out[M][N] (+)= alpha * sum_t A[t][m] B[t][n]
+# ---------------------------------------------------------------------------------------------
+def operand_rows(ld: int) -> L.OperandDesc:
+    return L.OperandDesc(0, ld, 0, 0, (L.i32 * 3)(0, 0, 0), 0)
+
+
+def operand_heads(rows: int, hd: int) -> L.OperandDesc:
+    """[T/rows][C/hd][rows][hd]: the layout of the attention kernels' q/k/v (and their gradients)."""
+    return L.OperandDesc(1, 0, rows, hd, (L.i32 * 3)(0, 0, 0), 0)
+
+
+def operand_conv_taps(dims: Sequence[int], cin: int, ld: int) -> L.OperandDesc:
+    return L.OperandDesc(2, ld, 0, 0, (L.i32 * 3)(*dims), cin)
+
+
+def gemm_tn(a: torch.Tensor, a_desc: L.OperandDesc, b: torch.Tensor, b_desc: L.OperandDesc, T: int, M: int, N: int,
+            out: Optional[torch.Tensor] = None, alpha: float = 1.0, accumulate: bool = False,
+            perm_cin: int = 0) -> torch.Tensor:
+    """fp32 [M, N] = alpha * A^T B over T tokens (bf16 operands described by a_desc / b_desc)."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.numel() == M * N
+    d = L.GemmTnDesc(T, M, N, a_desc, b_desc, alpha, 1 if accumulate else 0, perm_cin)
+    ws_bytes = L.lib().mivp_gemm_tn_ws(C.byref(d))
+    ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
+    L.call("mivp_gemm_tn", C.byref(d), L.ptr(a), L.ptr(b), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(out), L.stream())
+    return out

@@ -73,5 +73,6 @@ def test_cabi_exports_every_declared_symbol():
     assert not missing, missing
     assert lib.mivp_abi_version() == _lib.ABI_VERSION
     # descriptor layouts agree between the header's compiler and the ctypes mirror
-    for which, cls in enumerate([_lib.SwinDesc, _lib.MergeDesc, _lib.ConvDesc, _lib.EmbedDesc, _lib.UpcatDesc]):
+    for which, cls in enumerate([_lib.SwinDesc, _lib.MergeDesc, _lib.ConvDesc, _lib.EmbedDesc, _lib.UpcatDesc,
+                                 _lib.OperandDesc, _lib.GemmTnDesc]):
         assert lib.mivp_sizeof_desc(which) == ctypes.sizeof(cls), cls.__name__
