@@ -110,10 +110,12 @@ int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x,
 
 /* ---- backward of the block: data gradients + prompt / token-bias gradients ---- */
 /* dy [B, vol_out, C] bf16 -> dO [B*P][Nqp][C] bf16 and dt1 [B*P][Nqp][C] bf16
- *   wmlp_t = mlp.weight^T, wproj_t = proj.weight^T  ([in][out] -> rows are input channels) */
+ *   wmlp_t = mlp.weight^T, wproj_t = proj.weight^T  ([in][out] -> rows are input channels)
+ *   weight-gradient mode (both or neither, else NULL): dn_out [B*P][Nqp][C] bf16 = gradient w.r.t. the
+ *   mlp_norm output, dyw [B*P][Nqp][C] bf16 = dy in window order (zero rows where the token was cropped) */
 int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
                            const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
-                           void* d_o, void* d_t1, mivp_stream_t stream);
+                           void* d_o, void* d_t1, void* dn_out, void* dyw, mivp_stream_t stream);
 
 /* delta[bp][head][n] = sum_j dO * O  (flash-attention backward row term) */
 int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
@@ -133,19 +135,27 @@ int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const void* k, c
                           const void* kp, const void* vp, const void* qa, const void* ka,
                           const int32_t* tok_rid, const void* d_o, const float* lse, const float* delta,
                           void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
-                          mivp_stream_t stream);
+                          float* dka_part, mivp_stream_t stream);
+/*   dka_part (NULL or f32 [B*P][heads][Nkp][32]): per-window gradient of the key-side bias augmentation
+ *   columns (mivp_relbias_aug's ka); summed over windows and folded by mivp_relbias_grad into the
+ *   gradients of the three relative-position tables (relative_positional_encoding.py:99-142)       */
+int mivp_relbias_grad(const MivpSwinDesc* d, const float* dka /* [heads][Nkp][32] */, float* d_th, float* d_tw,
+                      float* d_td, mivp_stream_t stream);
 
 /* dq,dk,dv -> (x W^T backward) -> LayerNorm backward -> + dt1 -> scatter to dx [B, vol_in, C] bf16
- *   wqkv_t [C][3C] bf16 = stacked weight transposed; q part is multiplied by q_scale inside */
+ *   wqkv_t [C][3C] bf16 = stacked weight transposed; q part is multiplied by q_scale inside
+ *   dn_out (NULL or [B*P][Nqp][C] bf16): gradient w.r.t. the attn_norm output (weight-gradient mode) */
 int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv,
                       const void* x, const int32_t* tok_src, const float* ln_w, const float* ln_b,
-                      const void* wqkv_t, const void* d_t1, void* dx, mivp_stream_t stream);
+                      const void* wqkv_t, const void* d_t1, void* dx, void* dn_out, mivp_stream_t stream);
 
 /* prompt K/V gradients -> through to_k/to_v and LayerNorm -> dprompt [Np][C] f32
- *   dkp, dvp [heads][Npp][hd] f32 (already reduced over windows) ; wqkv [3C][C] bf16 */
+ *   dkp, dvp [heads][Npp][hd] f32 (already reduced over windows) ; wqkv [3C][C] bf16
+ *   weight-gradient mode (all three or NULL): wg_a [2][Np][C] bf16 = dK rows then dV rows (head-merged),
+ *   wg_n [Np][C] bf16 = attn_norm(prompt), wg_ln [2][Np][C] f32 = per-row dbeta terms then dgamma terms */
 int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const float* dvp, const float* prompt,
                        const float* ln_w, const float* ln_b, const void* wqkv, float* dprompt,
-                       mivp_stream_t stream);
+                       void* wg_a, void* wg_n, float* wg_ln, mivp_stream_t stream);
 
 /* out[r] = sum_i in[i][r]  for i < n, r < rows  (deterministic two-level tree) */
 int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream);
@@ -164,9 +174,12 @@ typedef struct MivpMergeDesc {
 /* x [B,H,W,D,C] bf16 -> y [B,oh,ow,od,Cout] bf16 ; w [Cout][kC] bf16 ; ln over kC */
 int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const float* ln_w, const float* ln_b,
                          const void* w, void* y, mivp_stream_t stream);
-/* dy -> dx ; w_t [kC][Cout] bf16 */
+/* dy -> dx ; w_t [kC][Cout] bf16
+ *   weight-gradient mode (both or NULL): wg_dn, wg_x [T][kC] bf16 = gradient w.r.t. the LayerNorm output and the
+ *   gathered LayerNorm input rows */
 int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
-                         const float* ln_b, const void* w_t, void* dx, mivp_stream_t stream);
+                         const float* ln_b, const void* w_t, void* dx, void* wg_dn, void* wg_x,
+                         mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* 3x3x3 stride-1 pad-1 convolution as implicit GEMM                         */
@@ -311,6 +324,16 @@ typedef struct MivpGemmTnDesc {
     int32_t perm_cin;   /* > 0 (== b.cin, mode 2): store column tap*cin + ci at ci*27 + tap,     */
                         /* i.e. out is nn.Conv3d.weight's [Cout][Cin][3][3][3]                   */
 } MivpGemmTnDesc;
+
+/* LayerNorm parameter gradients and the normalised rows the Linear weight gradients multiply with
+ * (nn.LayerNorm of swin_block.py:117-118, down.py:16): rows x[t] are read directly (tok_src NULL) or
+ * gathered through the block's tok_src table; dn = gradient w.r.t. the LayerNorm output.
+ *   stats  [T][2] f32 scratch;  n_out [T][C] bf16 = LN(x) (zero rows on padding slots);
+ *   part   [nblk][2C] f32: per-block (dbeta | dgamma) partials, reduce with mivp_reduce_rows;
+ *   (nblk*256) % (C/8) == 0 */
+int mivp_ln_wgrad(const void* x, const int32_t* tok_src, const void* dn, int64_t T, int32_t C, int32_t Nqp,
+                  int32_t P, int64_t vol, float eps, const float* gamma, const float* beta, float* stats,
+                  void* n_out, int32_t nblk, float* part, mivp_stream_t stream);
 
 size_t mivp_gemm_tn_ws(const MivpGemmTnDesc* d);   /* fp32 split partials */
 int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* b, void* workspace, size_t ws_bytes,

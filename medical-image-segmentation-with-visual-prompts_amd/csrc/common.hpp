@@ -75,6 +75,37 @@ struct OperandRows {
     }
 };
 
+// Deterministic block reduction of per-thread channel-group partials: thread t (global id gt) owns channel group
+// gt % G; its 16 partial sums (8 channels x {s1, s2}) go to LDS and one thread per output channel adds the owners
+// of that group in a fixed order.  (LDS float atomics would be shorter but their order changes run to run, and the
+// BatchNorm statistics feed everything downstream.)  smem: 256 * 16 floats.
+MIVP_DEV void block_reduce_groups(float* lds, const float (&s1)[8], const float (&s2)[8], int G, int C, long block_first_gtid,
+                                  float* __restrict__ out2c) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { lds[tid * 16 + i] = s1[i]; lds[tid * 16 + 8 + i] = s2[i]; }
+    __syncthreads();
+    for (int o = tid; o < 2 * C; o += 256) {
+        const int which = o / C, c = o - which * C, cg = c >> 3, i = c & 7;
+        int t0 = (int)(((long)cg - block_first_gtid % G + G) % G);      // first thread of this block that owns group cg
+        float acc = 0.f;
+        for (int t = t0; t < 256; t += G) acc += lds[t * 16 + which * 8 + i];
+        out2c[o] = acc;
+    }
+}
+
+// number of 256-thread blocks such that (blocks * 256) % G == 0 (every thread keeps one channel group)
+static inline unsigned fixed_group_grid(long items, int G, long cap) {
+    long want = (items + 255) / 256;
+    if (want > cap) want = cap;
+    long a = G, b = 256;
+    while (b) { const long t = a % b; a = b; b = t; }       // a = gcd(G, 256)
+    const long step = G / a;
+    long blocks = want / step * step;
+    if (blocks < step) blocks = step;
+    return (unsigned)blocks;
+}
+
 // error plumbing shared by the C-ABI translation units
 void mivp_set_error(const char* msg);
 int mivp_check_launch(const char* what);

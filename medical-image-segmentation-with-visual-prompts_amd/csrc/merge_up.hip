@@ -320,7 +320,10 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const bf16_t* __restrict__ dy,
                                                          const bf16_t* __restrict__ x, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, const bf16_t* __restrict__ w_t,
-                                                         bf16_t* __restrict__ dx) {
+                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ wg_dn,
+                                                         bf16_t* __restrict__ wg_x) {
+    // wg_dn / wg_x (optional, weight-gradient mode): [T][kC] gradient w.r.t. the LayerNorm output and the gathered
+    // (front-padded) LayerNorm input rows, the operands of mivp_ln_wgrad / mivp_gemm_tn
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, Cout = d.Cout;
@@ -395,6 +398,10 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
         const int c0 = 16 * ct + 4 * g;
         long so;
         const f32x4 v = load_x4(c0, so);
+        if (wg_dn && m.live && c0 < kC) {
+            st4(wg_dn + t * kC + c0, pack4(gy));
+            st4(wg_x + t * kC + c0, pack4(v));
+        }
         if (c0 < kC && so >= 0) {
             f32x4 out;
 #pragma unroll
@@ -405,15 +412,18 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
 }
 
 extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
-                                    const float* ln_b, const void* w_t, void* dx, mivp_stream_t stream) {
+                                    const float* ln_b, const void* w_t, void* dx, void* wg_dn, void* wg_x,
+                                    mivp_stream_t stream) {
     MIVP_REQUIRE(d && dy && x && ln_w && ln_b && w_t && dx);
+    MIVP_REQUIRE((wg_dn == nullptr) == (wg_x == nullptr));
     MIVP_REQUIRE(d->C % 8 == 0 && d->Cout % 8 == 0);
     const int NS = (d->Cout + 31) / 32;
     const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_MB(K) hipLaunchKernelGGL((k_patch_merge_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, \
-                                         (const bf16_t*)x, ln_w, ln_b, (const bf16_t*)w_t, (bf16_t*)dx)
+                                         (const bf16_t*)x, ln_w, ln_b, (const bf16_t*)w_t, (bf16_t*)dx, (bf16_t*)wg_dn,   \
+                                         (bf16_t*)wg_x)
     switch (NS) {
         case 1: LAUNCH_MB(1); break;
         case 2: LAUNCH_MB(2); break;

@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
                                                            const int* __restrict__ tok_dst, const bf16_t* __restrict__ t1,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                            const bf16_t* __restrict__ wmlp_t, const bf16_t* __restrict__ wproj_t,
-                                                           bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1) {
+                                                           bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1,
+                                                           bf16_t* __restrict__ dn_out, bf16_t* __restrict__ dyw) {
+    // dn_out / dyw (optional, weight-gradient mode): gradient w.r.t. the mlp_norm output and dy in window order
     constexpr int KS = (CT + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
         }
         dh[ct] = acc;
         const int n0 = 16 * ct + 4 * g;
+        if (dn_out && ti.live && n0 < C) st4(dn_out + ti.tt * (long)C + n0, pack4(acc));
         f32x4 v = fzero4();
         if (ti.live && n0 < C) { const bf16x4 raw = ld4(t1 + ti.tt * (long)C + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
         tv[ct] = v;
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
             if (n0 < C) {
                 f32x4 v = fzero4();
                 if (dst >= 0) { const bf16x4 raw = ld4(dyrow + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
+                if (dyw && ti.live) st4(dyw + ti.tt * (long)C + n0, pack4(v));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rstd * (dh[ct][j] - m1 - tv[ct][j] * m2);
                 out = pack4(v);
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 // Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int KPW, int NW>
-__global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
+template <int DKS, int DVT, int KPW, int NW, bool AUG>
+__global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
                                                           const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
@@ -383,16 +387,21 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16_t* __restrict__ dk,
                                                           bf16_t* __restrict__ dv, float* __restrict__ dkp_part,
-                                                          float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+                                                          float* __restrict__ dvp_part, float* __restrict__ dtok_part,
+                                                          float* __restrict__ dka_part) {
+    // AUG (weight-gradient mode): also accumulates dK' over the 32 bias-augmentation columns, i.e.
+    // dka_part[bph][key][a] = sum_n dS[n, key] * qa[n][a]  (f32 [B*P*heads][Nkp][32]): the window-local gradient of
+    // the relative-position-bias table values that mivp_relbias_aug laid out on the key side.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = AttnBwdGeom<DKS, DVT>;
     constexpr int DK = G::DK, DVS = G::DVS, DVP = G::DVP, QROW = G::KROW, OROW = G::VROWB;
+    constexpr int QTR = 16 * DVT + (AUG ? 32 : 0);            // rows of the transposed Q' image
     const int cq = chunk_tiles * 16;
     const int TROW = (cq + 8) * 2;
     char* Qimg = smem;
     char* Oimg = Qimg + (size_t)cq * QROW;
     char* Qt = Oimg + (size_t)cq * OROW;
-    char* Ot = Qt + (size_t)(16 * DVT) * TROW;
+    char* Ot = Qt + (size_t)QTR * TROW;
     float* lse_s = reinterpret_cast<float*>(Ot + (size_t)(16 * DVT) * TROW);
     float* del_s = lse_s + cq;
     int* ridq = reinterpret_cast<int*>(del_s + cq);
@@ -409,11 +418,13 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
     const int kstride = NW * gridDim.y;
     const int kfirst = kt0 + NW * blockIdx.y + wave;
 
-    f32x4 dkacc[KPW][DVT], dvacc[KPW][DVT];
+    f32x4 dkacc[KPW][DVT], dvacc[KPW][DVT], dkaug[KPW][2];
     float dtok[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         dtok[i] = 0.f;
+        dkaug[i][0] = fzero4();
+        dkaug[i][1] = fzero4();
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) { dkacc[i][dd] = fzero4(); dvacc[i][dd] = fzero4(); }
     }
@@ -435,7 +446,18 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<bf16_t*>(Qt + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = (c4 < hd4) ? val[i] : (bf16_t)0.0f;
             }
+            if (AUG && c4 >= hd4 && c4 < hd4 + a4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<bf16_t*>(Qt + (size_t)(16 * DVT + 4 * (c4 - hd4) + i) * TROW + 2 * lrow) = val[i];
+            }
             *reinterpret_cast<bf16x4*>(Qimg + G::KR::off(lrow, 4 * c4)) = val;
+        }
+        if (AUG) {                                             // augmentation rows A .. 31 of the transposed image are zero
+            for (int e = tid; e < (32 - A) * nq; e += 64 * NW) {
+                const int rr = 16 * DVT + A + e / nq, col = e % nq;
+                *reinterpret_cast<bf16_t*>(Qt + (size_t)rr * TROW + 2 * col) = (bf16_t)0.0f;
+            }
         }
         for (int e = tid; e < nq * dvp4; e += 64 * NW) {
             const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
@@ -543,6 +565,24 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
                     dkacc[i][dd] = mfma16(aq, sb, dkacc[i][dd]);
                     dvacc[i][dd] = mfma16(ao, pb, dvacc[i][dd]);
                 }
+                if (AUG) {
+                    // The table gradients are signed sums of dS with heavy cancellation (each softmax row of dS sums
+                    // to zero), so dS enters this product as a bf16 hi + lo pair (qa is an exact one-hot).
+                    f32x4 lo[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lo[hh][j] = ds[hh][j] - (float)(bf16_t)ds[hh][j];
+                    const bf16x8 sb_lo = cat44(pack4(lo[0]), pack4(lo[1]));
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd) {
+                        const char* arow_t = Qt + (size_t)(16 * DVT + 16 * dd + r) * TROW;
+                        const bf16x8 aa = cat44(*reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 4 * g) * 2),
+                                                *reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 16 + 4 * g) * 2));
+                        dkaug[i][dd] = mfma16(aa, sb, dkaug[i][dd]);
+                        dkaug[i][dd] = mfma16(aa, sb_lo, dkaug[i][dd]);
+                    }
+                }
             }
         }
     }
@@ -552,6 +592,11 @@ __global__ __launch_bounds__(64 * NW, DKS == 1 ? 4 : 2) void k_win_attn_bwd_dkv(
         if (kt >= nt) continue;
         const int krow = kt * 16 + r;
         const float dt = col_sum(dtok[i]);
+        if (AUG) {
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+                *reinterpret_cast<f32x4*>(dka_part + ((bph * Nkp + krow) * 32 + 16 * dd + 4 * g)) = dkaug[i][dd];
+        }
         if (krow < Nqp) {
             if (dk && dv) {
 #pragma unroll
@@ -587,7 +632,8 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
                                                       const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                       const bf16_t* __restrict__ wqkv_t, const bf16_t* __restrict__ d_t1,
-                                                      bf16_t* __restrict__ dx) {
+                                                      bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out) {
+    // dn_out (optional, weight-gradient mode): gradient w.r.t. the attn_norm output, window order
     constexpr int KS3 = (3 * 16 * CT + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -631,6 +677,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
         }
         dyv[ct] = acc;
         const int c0 = 16 * ct + 4 * g;
+        if (dn_out && ti.live && c0 < C) st4(dn_out + ti.tt * (long)C + c0, pack4(acc));
         f32x4 xx = fzero4();
         if (src >= 0 && c0 < C) { const bf16x4 raw = ld4(x + ((ti.b * d.vol_in + src) * (long)C + c0)); for (int j = 0; j < 4; ++j) xx[j] = (float)raw[j]; }
         xv[ct] = xx;
@@ -681,7 +728,11 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
 __global__ __launch_bounds__(256) void k_prompt_kv_bwd(MivpSwinDesc d, const float* __restrict__ dkp,
                                                        const float* __restrict__ dvp, const float* __restrict__ prompt,
                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                       const bf16_t* __restrict__ wqkv, float* __restrict__ dprompt) {
+                                                       const bf16_t* __restrict__ wqkv, float* __restrict__ dprompt,
+                                                       bf16_t* __restrict__ wg_a, bf16_t* __restrict__ wg_n,
+                                                       float* __restrict__ wg_ln) {
+    // weight-gradient mode (all three or none): wg_a [2][Np][C] bf16 = dK rows, dV rows (head-merged), wg_n [Np][C] bf16 =
+    // LN(prompt) (the to_k / to_v input), wg_ln [2][Np][C] f32 = per-row dbeta terms, dgamma terms of attn_norm
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gk = reinterpret_cast<float*>(smem);            // [C] dK row (head-merged)
     float* gv = gk + d.C;                                    // [C]
@@ -715,6 +766,13 @@ __global__ __launch_bounds__(256) void k_prompt_kv_bwd(MivpSwinDesc d, const flo
             acc += gk[n] * (float)wqkv[(long)(C + n) * C + c] + gv[n] * (float)wqkv[(long)(2 * C + n) * C + c];
         const float dxh = acc * ln_w[c];
         const float xh = (prompt[(long)t * C + c] - mean) * rstd;
+        if (wg_a) {
+            wg_a[(long)t * C + c] = (bf16_t)gk[c];
+            wg_a[((long)d.Np + t) * C + c] = (bf16_t)gv[c];
+            wg_n[(long)t * C + c] = (bf16_t)(xh * ln_w[c] + ln_b[c]);
+            wg_ln[(long)t * C + c] = acc;
+            wg_ln[((long)d.Np + t) * C + c] = acc * xh;
+        }
         dxh_loc[cnt] = dxh;
         xh_loc[cnt] = xh;
         s1 += dxh;
@@ -754,16 +812,17 @@ static int bwd_checks(const MivpSwinDesc* d) {
 
 extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
                                       const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
-                                      void* d_o, void* d_t1, mivp_stream_t stream) {
+                                      void* d_o, void* d_t1, void* dn_out, void* dyw, mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(dy && tok_dst && t1 && ln_w && ln_b && wmlp_t && wproj_t && d_o && d_t1);
+    MIVP_REQUIRE((dn_out == nullptr) == (dyw == nullptr));
     const long T = (long)d->B * d->P * d->Nqp;
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
 #define L_PMB(K) hipLaunchKernelGGL((k_swin_proj_mlp_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, tok_dst, \
                                      (const bf16_t*)t1, ln_w, ln_b, (const bf16_t*)wmlp_t, (const bf16_t*)wproj_t,          \
-                                     (bf16_t*)d_o, (bf16_t*)d_t1)
+                                     (bf16_t*)d_o, (bf16_t*)d_t1, (bf16_t*)dn_out, (bf16_t*)dyw)
     CT_SWITCH((d->C + 15) / 16, L_PMB)
 #undef L_PMB
     return mivp_check_launch("swin_proj_mlp_bwd");
@@ -832,14 +891,14 @@ extern "C" int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const 
     return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
 }
 
-template <int DKS, int DVT, int KPW>
+template <int DKS, int DVT, int KPW, bool AUG>
 static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
                       const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
                       const float* delta, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
-                      hipStream_t st) {
+                      float* dka_part, hipStream_t st) {
     using G = AttnBwdGeom<DKS, DVT>;
-    const size_t per_tile = 16 * (size_t)G::KROW + 16 * (size_t)G::VROWB + 2 * (size_t)16 * DVT * 32 + 3 * 64;
-    const size_t fixed = 2 * (size_t)16 * DVT * 16;
+    const size_t per_tile = 16 * (size_t)G::KROW + 16 * (size_t)G::VROWB + 2 * (size_t)16 * DVT * 32 + 3 * 64 + (AUG ? 32 * 32 : 0);
+    const size_t fixed = 2 * (size_t)16 * DVT * 16 + (AUG ? 32 * 16 : 0);
     const int nqt = (d->Nqp + 31) / 32 * 2;
     const int chunk = pick_chunk(nqt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
@@ -849,36 +908,45 @@ static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const
     if (ktiles <= 0) return MIVP_OK;
     constexpr int NW = 8;
     const int ksplit = (ktiles + NW * KPW - 1) / (NW * KPW);
-    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW>;
+    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o,
-                       lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part, dvp_part, dtok_part);
+                       lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkp_part, dvp_part, dtok_part, dka_part);
     return mivp_check_launch("win_attn_bwd_dkv");
 }
 
 extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                                      const void* vp, const void* qa, const void* ka, const int32_t* tok_rid,
                                      const void* d_o, const float* lse, const float* delta, void* dk, void* dv,
-                                     float* dkp_part, float* dvp_part, float* dtok_part, mivp_stream_t stream) {
+                                     float* dkp_part, float* dvp_part, float* dtok_part, float* dka_part,
+                                     mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(q && k && v && qa && ka && d_o && lse && delta);
     MIVP_REQUIRE((dk == nullptr) == (dv == nullptr));
     MIVP_REQUIRE(d->Np == 0 || (kp && vp && dkp_part && dvp_part && dtok_part));
     MIVP_REQUIRE(!d->has_mask || tok_rid);
+    MIVP_REQUIRE(dka_part == nullptr || (dk != nullptr && d->augp <= 32));
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (dks == 1) return launch_dkv<1, 1, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    if (dks == 2) return launch_dkv<2, 2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
-    return launch_dkv<3, 3, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, st);
+#define DKV_ARGS d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, dka_part, st
+    if (dka_part) {
+        if (dks == 1) return launch_dkv<1, 1, 2, true>(DKV_ARGS);
+        if (dks == 2) return launch_dkv<2, 2, 2, true>(DKV_ARGS);
+        return launch_dkv<3, 3, 1, true>(DKV_ARGS);
+    }
+    if (dks == 1) return launch_dkv<1, 1, 2, false>(DKV_ARGS);
+    if (dks == 2) return launch_dkv<2, 2, 2, false>(DKV_ARGS);
+    return launch_dkv<3, 3, 1, false>(DKV_ARGS);
+#undef DKV_ARGS
 }
 
 extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x,
                                  const int32_t* tok_src, const float* ln_w, const float* ln_b, const void* wqkv_t,
-                                 const void* d_t1, void* dx, mivp_stream_t stream) {
+                                 const void* d_t1, void* dx, void* dn_out, mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(dq && dk && dv && x && tok_src && ln_w && ln_b && wqkv_t && d_t1 && dx);
@@ -887,7 +955,7 @@ extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const vo
     hipStream_t st = (hipStream_t)stream;
 #define L_QB(K) hipLaunchKernelGGL((k_swin_qkv_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dq, (const bf16_t*)dk, \
                                     (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, ln_b, (const bf16_t*)wqkv_t,             \
-                                    (const bf16_t*)d_t1, (bf16_t*)dx)
+                                    (const bf16_t*)d_t1, (bf16_t*)dx, (bf16_t*)dn_out)
     CT_SWITCH((d->C + 15) / 16, L_QB)
 #undef L_QB
     return mivp_check_launch("swin_qkv_bwd");
@@ -895,13 +963,14 @@ extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const vo
 
 extern "C" int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const float* dvp, const float* prompt,
                                   const float* ln_w, const float* ln_b, const void* wqkv, float* dprompt,
-                                  mivp_stream_t stream) {
+                                  void* wg_a, void* wg_n, float* wg_ln, mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(d->Np > 0 && dkp && dvp && prompt && ln_w && ln_b && wqkv && dprompt);
+    MIVP_REQUIRE((wg_a == nullptr) == (wg_n == nullptr) && (wg_a == nullptr) == (wg_ln == nullptr));
     MIVP_REQUIRE(d->C <= 1024);
     hipLaunchKernelGGL(k_prompt_kv_bwd, dim3(d->Np), dim3(256), (2 * d->C + 16) * sizeof(float), (hipStream_t)stream, *d,
-                       dkp, dvp, prompt, ln_w, ln_b, (const bf16_t*)wqkv, dprompt);
+                       dkp, dvp, prompt, ln_w, ln_b, (const bf16_t*)wqkv, dprompt, (bf16_t*)wg_a, (bf16_t*)wg_n, wg_ln);
     return mivp_check_launch("prompt_kv_bwd");
 }
 

@@ -233,3 +233,159 @@ extern "C" int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* 
                        (const float*)workspace, splits, d->M, d->N, d->alpha, d->accumulate, d->perm_cin, out);
     return mivp_check_launch("mivp_gemm_tn");
 }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm parameter gradients + the normalised rows the Linear weight gradients need.
+//   rows x[t] (direct, or gathered through the block's tok_src table like mivp_swin_qkv_fwd does),
+//   dn[t] = gradient w.r.t. the LayerNorm OUTPUT (before gamma is applied backwards), emitted by the
+//   fused backward kernels.
+//   pass 1  k_ln_rowstats : (mean, rstd) per row; rstd = -1 marks padding slots (tok_src == -2)
+//   pass 2  k_ln_wgrad    : n[t] = xhat*gamma + beta (bf16, the B operand of mivp_gemm_tn; zero on padding
+//                           slots), per-block partials of dgamma = sum dn*xhat and dbeta = sum dn.  Every
+//                           thread keeps one 8-channel group, blocks reduce in a fixed order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct LnRow { const bf16_t* p; int cls; };     // cls: 0 data row, 1 zero row (window zero-pad), 2 padding slot
+
+MIVP_DEV LnRow ln_row(const bf16_t* __restrict__ x, const int* __restrict__ tok_src, long t, int C, int Nqp, int P, long vol) {
+    LnRow r;
+    r.cls = 0;
+    r.p = x + t * C;
+    if (tok_src) {
+        const long bp = t / Nqp;
+        const int slot = (int)(t - bp * Nqp);
+        const int pw = (int)(bp % P);
+        const long b = bp / P;
+        const int src = tok_src[pw * Nqp + slot];
+        r.cls = src >= 0 ? 0 : (src == -1 ? 1 : 2);
+        r.p = x + (b * vol + (src >= 0 ? src : 0)) * C;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_ln_rowstats(const bf16_t* __restrict__ x, const int* __restrict__ tok_src, long T, int C,
+                                                     int Nqp, int P, long vol, float eps, float* __restrict__ stats) {
+    const int l16 = threadIdx.x & 15;
+    const long t = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = t < T;
+    LnRow row = ln_row(x, tok_src, ok ? t : 0, C, Nqp, P, vol);
+    float s = 0.f;
+    if (ok && row.cls == 0)
+        for (int c4 = l16; c4 < C / 4; c4 += 16) { const bf16x4 v = ld4(row.p + 4 * c4); s += (float)v[0] + (float)v[1] + (float)v[2] + (float)v[3]; }
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    if (ok && row.cls == 0)
+        for (int c4 = l16; c4 < C / 4; c4 += 16) {
+            const bf16x4 v = ld4(row.p + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dlt = (float)v[j] - mean; q += dlt * dlt; }
+        }
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (ok && l16 == 0) {
+        stats[2 * t] = mean;
+        stats[2 * t + 1] = row.cls == 2 ? -1.f : rsqrtf(q / (float)C + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ln_wgrad(const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
+                                                  const bf16_t* __restrict__ dn, const float* __restrict__ stats, long T, int C,
+                                                  int Nqp, int P, long vol, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, bf16_t* __restrict__ n_out,
+                                                  float* __restrict__ part) {
+    __shared__ float lsum[256 * 16];
+    const int G = C / 8;
+    const long items = T * G;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
+    float gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gm[i] = gamma[cg * 8 + i]; bt[i] = beta[cg * 8 + i]; s1[i] = 0.f; s2[i] = 0.f; }
+    for (long it = gtid; it < items; it += stride) {
+        const long t = it / G;
+        const float mean = stats[2 * t], rstd = stats[2 * t + 1];
+        bf16x8 nv = zero8();
+        if (rstd >= 0.f) {
+            const LnRow row = ln_row(x, tok_src, t, C, Nqp, P, vol);
+            const bf16x8 xv = row.cls == 0 ? ld8(row.p + cg * 8) : zero8();
+            const bf16x8 dv = ld8(dn + t * C + cg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = ((float)xv[i] - mean) * rstd;
+                const float g = (float)dv[i];
+                nv[i] = (bf16_t)(xh * gm[i] + bt[i]);
+                s1[i] += g;               // dbeta
+                s2[i] += g * xh;          // dgamma
+            }
+        }
+        st8(n_out + t * C + cg * 8, nv);
+    }
+    block_reduce_groups(lsum, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
+}
+
+// Relative-position-bias table gradients from the window-summed gradient of the K' augmentation columns
+// (mivp_relbias_aug's layout).  dka [heads][Nkp][32] f32.  One thread per table entry walks every (key, column)
+// that read it: deterministic, ~7k terms per entry.
+__global__ __launch_bounds__(64) void k_relbias_grad(MivpSwinDesc d, const float* __restrict__ dka, float* __restrict__ d_th,
+                                                     float* __restrict__ d_tw, float* __restrict__ d_td) {
+    const int head = blockIdx.x;
+    const int w0 = d.win[0], w1 = d.win[1], w2 = d.win[2];
+    const int n0 = 2 * w0 - 1, n1 = 2 * w1 - 1, n2 = 2 * w2 - 1;
+    const float* g = dka + (long)head * d.Nkp * 32;
+    for (int e = threadIdx.x; e < n0 + n1 + n2; e += 64) {
+        float acc = 0.f;
+        if (e < n0) {
+            for (int m = 0; m < d.Nq; ++m) {
+                const int k0 = m / (w2 * w1);
+                const int a = k0 + w0 - 1 - e;                       // th[k0 - a + w0 - 1] == th[e]
+                if (a >= 0 && a < w0) acc += g[m * 32 + a];
+            }
+            d_th[head * n0 + e] = acc;
+        } else if (e < n0 + n1) {
+            const int ee = e - n0;
+            for (int m = 0; m < d.Nq; ++m) {
+                const int k1 = (m / w2) % w1;
+                const int a = k1 + w1 - 1 - ee;
+                if (a >= 0 && a < w1) acc += g[m * 32 + w0 + a];
+            }
+            d_tw[head * n1 + ee] = acc;
+        } else {
+            const int ee = e - n0 - n1;
+            for (int m = 0; m < d.Nq; ++m) {
+                const int k2 = m % w2;
+                const int a = k2 + w2 - 1 - ee;                      // query i2 = a < w2 - 1 has its own column
+                if (a >= 0 && a < w2 - 1) acc += g[m * 32 + w0 + w1 + a];
+                if (k2 == ee) {                                      // the folded i2 = w2-1 term: + every i0 column, - every i2 column
+                    for (int c = 0; c < w0; ++c) acc += g[m * 32 + c];
+                    for (int c = 0; c < w2 - 1; ++c) acc -= g[m * 32 + w0 + w1 + c];
+                }
+            }
+            d_td[head * n2 + ee] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mivp_ln_wgrad(const void* x, const int32_t* tok_src, const void* dn, int64_t T, int32_t C, int32_t Nqp,
+                             int32_t P, int64_t vol, float eps, const float* gamma, const float* beta, float* stats,
+                             void* n_out, int32_t nblk, float* part, mivp_stream_t stream) {
+    MIVP_REQUIRE(x && dn && gamma && beta && stats && n_out && part && T > 0 && C > 0 && C % 8 == 0);
+    MIVP_REQUIRE(tok_src == nullptr || (Nqp > 0 && P > 0 && vol > 0 && T % Nqp == 0));
+    MIVP_REQUIRE(nblk > 0 && ((long)nblk * 256) % (C / 8) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ln_rowstats, dim3((unsigned)((T + 15) / 16)), dim3(256), 0, st, (const bf16_t*)x, tok_src, (long)T,
+                       (int)C, (int)Nqp, (int)P, (long)vol, eps, stats);
+    hipLaunchKernelGGL(k_ln_wgrad, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, tok_src, (const bf16_t*)dn,
+                       (const float*)stats, (long)T, (int)C, (int)Nqp, (int)P, (long)vol, gamma, beta, (bf16_t*)n_out, part);
+    return mivp_check_launch("mivp_ln_wgrad");
+}
+
+extern "C" int mivp_relbias_grad(const MivpSwinDesc* d, const float* dka, float* d_th, float* d_tw, float* d_td,
+                                 mivp_stream_t stream) {
+    MIVP_REQUIRE(d && dka && d_th && d_tw && d_td && d->augp <= 32);
+    hipLaunchKernelGGL(k_relbias_grad, dim3(d->heads), dim3(64), 0, (hipStream_t)stream, *d, dka, d_th, d_tw, d_td);
+    return mivp_check_launch("mivp_relbias_grad");
+}

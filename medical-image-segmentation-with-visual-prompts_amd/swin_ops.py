@@ -152,9 +152,42 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     return y, None
 
 
+def _colsum_bf16(x2d: torch.Tensor) -> torch.Tensor:
+    """Column sums of a bf16 [rows, C] matrix (f32 [C]) with the BatchNorm statistics kernel (fixed-order sums)."""
+    from . import ops
+    rows, Cc = x2d.shape
+    nblk = ops._nblk(rows * (Cc // 8), Cc // 8)
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x2d.device)
+    L.call("mivp_bn_stats", L.ptr(x2d), C.c_int64(rows), C.c_int32(Cc), C.c_int32(nblk), L.ptr(part), L.stream())
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=x2d.device)
+    L.call("mivp_reduce_rows", L.ptr(part), C.c_int64(nblk), C.c_int64(2 * Cc), L.ptr(sums), L.stream())
+    return sums[:Cc]
+
+
+def ln_wgrad(x: torch.Tensor, dn: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, T: int, Cc: int,
+             tok_src: Optional[torch.Tensor] = None, Nqp: int = 0, P: int = 0, vol: int = 0):
+    """LayerNorm parameter gradients.  Returns (n [T, C] bf16 = LN(x) rows, dgamma, dbeta)."""
+    from . import ops
+    dev = dn.device
+    stats = torch.empty((T, 2), dtype=torch.float32, device=dev)
+    n = torch.empty((T, Cc), dtype=BF16, device=dev)
+    nblk = ops._nblk(T * (Cc // 8), Cc // 8)
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dev)
+    L.call("mivp_ln_wgrad", L.ptr(x), L.ptr(tok_src), L.ptr(dn), C.c_int64(T), C.c_int32(Cc), C.c_int32(Nqp), C.c_int32(P),
+           C.c_int64(vol), C.c_float(eps), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(n), C.c_int32(nblk), L.ptr(part),
+           L.stream())
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+    L.call("mivp_reduce_rows", L.ptr(part), C.c_int64(nblk), C.c_int64(2 * Cc), L.ptr(sums), L.stream())
+    return n, sums[Cc:], sums[:Cc]
+
+
 def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[torch.Tensor], dy: torch.Tensor,
-                        need_dx: bool, need_prompt: bool):
-    """Backward of ``swin_block_forward``: returns (dx | None, dprompt | None, dts | None).
+                        need_dx: bool, need_prompt: bool, need_w: bool = False):
+    """Backward of ``swin_block_forward``: returns (dx | None, dprompt | None, dts | None[, wg]).
+
+    ``need_w``: also the gradients of the block's own parameters, returned as a dict ``wg`` (f32):
+    ln1_w, ln1_b, wq, wk, wv, wproj, bproj, ln2_w, ln2_b, wmlp, bmlp and the three relative-position tables
+    t_h, t_w, t_d ``[heads, 2w-1]`` (autograd carries those into ``pe.weights_content_*`` / ``pe.enc_content_*``).
 
     ``dts`` is the gradient of the ``[heads, Np]`` prompt-token bias scores; autograd carries it into
     ``pe.weights_token`` / ``pe.enc_token``.  When ``need_dx`` is False (first prompted block behind a frozen
@@ -167,10 +200,27 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
     Cc, heads = d.C, d.heads
     hd = Cc // heads
     BP = d.B * d.P
+    from . import ops
+    T = BP * d.Nqp
+    if need_w:
+        need_dx = True                                   # the weight gradients need the full attention backward
+        need_prompt = d.Np > 0
     d_o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
     d_t1 = torch.empty_like(d_o)
+    dn2 = torch.empty_like(d_o) if need_w else None
+    dyw = torch.empty_like(d_o) if need_w else None
     L.call("mivp_swin_proj_mlp_bwd", C.byref(d), L.ptr(dy), L.ptr(tb.tok_dst), L.ptr(sv.t1), L.ptr(w.ln2_w), L.ptr(w.ln2_b),
-           L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), st)
+           L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), L.ptr(dn2), L.ptr(dyw), st)
+    wg = None
+    if need_w:
+        wg = {}
+        rows = ops.operand_rows(Cc)
+        n2, wg["ln2_w"], wg["ln2_b"] = ln_wgrad(sv.t1, dn2, w.ln2_w, w.ln2_b, d.ln_eps, T, Cc)
+        wg["wmlp"] = ops.gemm_tn(dyw, rows, n2, rows, T, Cc, Cc)
+        wg["bmlp"] = _colsum_bf16(dyw.view(T, Cc))
+        wg["wproj"] = ops.gemm_tn(d_t1, rows, sv.o, rows, T, Cc, Cc)
+        wg["bproj"] = _colsum_bf16(d_t1.view(T, Cc))
+        del n2, dn2, dyw
     delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
     dx = dprompt = dts = None
     dk = dv = None
@@ -194,13 +244,32 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
             dkp_part = torch.empty((BP * heads, d.Npp, hd), dtype=torch.float32, device=dev)
             dvp_part = torch.empty_like(dkp_part)
             dtok_part = torch.empty((BP * heads, d.Npp), dtype=torch.float32, device=dev)
+        dka_part = torch.empty((BP * heads, d.Nkp, 32), dtype=torch.float32, device=dev) if need_w else None
         L.call("mivp_win_attn_bwd_dkv", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
                L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dk), L.ptr(dv),
-               L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), st)
+               L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), L.ptr(dka_part), st)
+        if need_w:
+            dka = torch.empty((heads, d.Nkp, 32), dtype=torch.float32, device=dev)
+            L.call("mivp_reduce_rows", L.ptr(dka_part), C.c_int64(BP), C.c_int64(heads * d.Nkp * 32), L.ptr(dka), st)
+            del dka_part
+            win = [int(d.win[a]) for a in range(3)]
+            tabs = [torch.empty((heads, 2 * win[a] - 1), dtype=torch.float32, device=dev) for a in range(3)]
+            L.call("mivp_relbias_grad", C.byref(d), L.ptr(dka), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]), st)
+            wg["t_h"], wg["t_w"], wg["t_d"] = tabs
     if need_dx:
         dx = torch.empty_like(sv.x)
+        dn1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if need_w else None
         L.call("mivp_swin_qkv_bwd", C.byref(d), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(sv.x), L.ptr(tb.tok_src),
-               L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv_t), L.ptr(d_t1), L.ptr(dx), st)
+               L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv_t), L.ptr(d_t1), L.ptr(dx), L.ptr(dn1), st)
+        if need_w:
+            n1, wg["ln1_w"], wg["ln1_b"] = ln_wgrad(sv.x, dn1, w.ln1_w, w.ln1_b, d.ln_eps, T, Cc, tok_src=tb.tok_src,
+                                                    Nqp=d.Nqp, P=d.P, vol=d.vol_in)
+            rows = ops.operand_rows(Cc)
+            hs = ops.operand_heads(d.Nqp, hd)
+            wg["wq"] = ops.gemm_tn(dq, hs, n1, rows, T, Cc, Cc, alpha=float(d.q_scale))
+            wg["wk"] = ops.gemm_tn(dk, hs, n1, rows, T, Cc, Cc)
+            wg["wv"] = ops.gemm_tn(dv, hs, n1, rows, T, Cc, Cc)
+            del n1, dn1
     if has_prompt and need_prompt:
         rows = heads * d.Npp * hd
         dkp = torch.empty((heads, d.Npp, hd), dtype=torch.float32, device=dev)
@@ -211,7 +280,23 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
         L.call("mivp_reduce_rows", L.ptr(dtok_part), C.c_int64(BP), C.c_int64(heads * d.Npp), L.ptr(dtok), st)
         pr = prompt.detach().to(torch.float32).contiguous()
         dprompt = torch.empty_like(pr)
+        wg_a = wg_n = wg_ln = None
+        if need_w:
+            wg_a = torch.empty((2, d.Np, Cc), dtype=BF16, device=dev)
+            wg_n = torch.empty((d.Np, Cc), dtype=BF16, device=dev)
+            wg_ln = torch.empty((2, d.Np, Cc), dtype=torch.float32, device=dev)
         L.call("mivp_prompt_kv_bwd", C.byref(d), L.ptr(dkp), L.ptr(dvp), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b),
-               L.ptr(w.wqkv), L.ptr(dprompt), st)
+               L.ptr(w.wqkv), L.ptr(dprompt), L.ptr(wg_a), L.ptr(wg_n), L.ptr(wg_ln), st)
         dts = dtok[:, :d.Np].contiguous()
+        if need_w:                                       # the prompt rows also pass through attn_norm, to_k and to_v
+            rows = ops.operand_rows(Cc)
+            ops.gemm_tn(wg_a[0], rows, wg_n, rows, d.Np, Cc, Cc, out=wg["wk"], accumulate=True)
+            ops.gemm_tn(wg_a[1], rows, wg_n, rows, d.Np, Cc, Cc, out=wg["wv"], accumulate=True)
+            ln_rows = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            L.call("mivp_reduce_rows", L.ptr(wg_ln[0]), C.c_int64(d.Np), C.c_int64(Cc), L.ptr(ln_rows[0]), st)
+            L.call("mivp_reduce_rows", L.ptr(wg_ln[1]), C.c_int64(d.Np), C.c_int64(Cc), L.ptr(ln_rows[1]), st)
+            wg["ln1_b"] = wg["ln1_b"] + ln_rows[0]
+            wg["ln1_w"] = wg["ln1_w"] + ln_rows[1]
+    if need_w:
+        return dx, dprompt, dts, wg
     return dx, dprompt, dts

@@ -108,6 +108,91 @@ def test_block_backward_real_sizes(window, dims, C, heads, n_prompt, shift, need
         assert err < 1.5e-2, (k, err)
 
 
+WEIGHT_KEYS = {"ln1_w": "attn_norm.weight", "ln1_b": "attn_norm.bias", "wq": "attn.to_q.weight", "wk": "attn.to_k.weight",
+               "wv": "attn.to_v.weight", "wproj": "attn.proj.weight", "bproj": "attn.proj.bias", "ln2_w": "mlp_norm.weight",
+               "ln2_b": "mlp_norm.bias", "wmlp": "mlp.weight", "bmlp": "mlp.bias"}
+
+
+def _run_block_weight_grads(sd, x, prm, gout, window, shift, heads):
+    """All parameter gradients of one block (the *_all / *_decoder training modes) vs autograd over the oracle."""
+    import mivp_amd
+    from mivp_amd import swin_ops
+    from oracle import swin_ref as S
+    n_prompt = 0 if prm is None else prm.shape[0]
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.is_floating_point() and (n_prompt or "token" not in k):
+            v.requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    po = prm.clone().requires_grad_(True) if prm is not None else None
+    S.swin_block(xo, po, sdo, "", window, shift, heads).backward(gout)
+
+    w = swin_ops.weights_from_state(sd, "", heads, 64, 0, torch.device(DEV), need_bwd=True)
+    leafs = {k: sd[k].clone().to(DEV).requires_grad_(True) for k in sd if k.startswith("pe.") and sd[k].is_floating_point()}
+    scale = 64 ** -0.5
+    tabs = [(leafs[f"pe.weights_content_{a}"] @ leafs[f"pe.enc_content_{a}"].t()) * (scale / 3.0) for a in "hwd"]
+    ts = None
+    if n_prompt:
+        ts = (leafs["pe.weights_token"] @ leafs["pe.enc_token.0"].t())[:, :n_prompt] * scale
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = None if prm is None else prm.to(DEV)
+    y, saved = swin_ops.swin_block_forward(xc, pd, w, ts, window, shift, save=True)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dx, dprompt, dts, wg = swin_ops.swin_block_backward(saved, w, pd, dy, True, n_prompt > 0, need_w=True)
+    torch.cuda.synchronize()
+    res = {"dx": rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), xo.grad)}
+    for short, key in WEIGHT_KEYS.items():
+        assert torch.isfinite(wg[short]).all(), short
+        res[key] = rel_l2(wg[short].cpu().reshape(sdo[key].shape), sdo[key].grad)
+    torch.autograd.backward(tabs + ([ts] if n_prompt else []), [wg["t_h"], wg["t_w"], wg["t_d"]] + ([dts] if n_prompt else []))
+    for k, leaf in leafs.items():
+        if sdo[k].grad is not None:
+            res[k] = rel_l2(leaf.grad.cpu(), sdo[k].grad)
+    if n_prompt:
+        res["dprompt"] = rel_l2(dprompt.cpu(), po.grad)
+    return res
+
+
+@pytest.mark.parametrize("tag", BLOCKS)
+def test_block_weight_gradients_golden_shapes(tag):
+    """Tolerance 1.5e-2 rel-L2 as for dx: the operands of every weight-gradient product are bf16-rounded
+    activations / activation gradients; the sums themselves are fp32.  The relative-position table gradients get
+    3e-2: they are signed sums of dS over a handful of windows in these toy shapes, and every softmax row of dS sums
+    to zero, so the bf16 rounding of q / k / dO upstream is amplified by the cancellation (measured 0.2-1.7e-2)."""
+    fx = load_fixture(f"block_{tag}")
+    m = fx.meta
+    sd = _rounded_state(fx["sd"])
+    res = _run_block_weight_grads(sd, r16(fx["in"]["x"]), fx["in"].get("prompt"), r16(fx["in"]["gout"]), m["window"],
+                                  m["shift"], m["heads"])
+    for k, err in res.items():
+        assert err < (3e-2 if "content" in k else 1.5e-2), (tag, k, err)
+
+
+@pytest.mark.parametrize("window,dims,C,heads,n_prompt,shift", [
+    ((7, 7, 7), (14, 14, 14), 48, 4, 64, (3, 3, 3)),
+    ((7, 7, 7), (12, 12, 24), 96, 8, 0, (0, 0, 0)),
+    ((7, 7, 7), (6, 6, 24), 192, 4, 64, (3, 3, 3)),       # decoder with prompts, hd 48
+    ((8, 8, 4), (16, 16, 8), 48, 4, 64, (4, 4, 2)),
+])
+def test_block_weight_gradients_real_sizes(window, dims, C, heads, n_prompt, shift):
+    from oracle.unetr_ref import _block_state
+    gen = torch.Generator().manual_seed(5)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, max(n_prompt, 1), n_prompt > 0, gen)
+    for k in list(sd):
+        if "norm.weight" in k:
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=gen)
+        if "norm.bias" in k or k.endswith("proj.bias") or k.endswith("mlp.bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=gen)
+    sd = _rounded_state(sd)
+    x = r16(torch.randn(2, C, *dims, generator=gen))
+    prm = 0.5 * torch.randn(n_prompt, C, generator=gen) if n_prompt else None
+    gout = r16(torch.randn(2, C, *dims, generator=gen))
+    res = _run_block_weight_grads(sd, x, prm, gout, window, shift, heads)
+    for k, err in res.items():
+        assert err < 1.5e-2, (k, err)
+
+
 @pytest.mark.parametrize("tag", ["even_T", "odd_T", "even_F", "odd_F"])
 def test_patch_merge_backward_golden(tag):
     import mivp_amd
