@@ -245,6 +245,9 @@ typedef struct MivpEmbedDesc {
  * mode 1: y = (conv(x)+bias) * scale + shift -> bf16 [B,h,w,d,C]                        */
 int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x, const float* w, const float* bias,
                      const float* scale, const float* shift, float* part, void* y, mivp_stream_t stream);
+/* bf16 im2col of the 2x2x2 patches, p [B*(H/2)*(W/2)*(D/2)][Cin*8] with columns in nn.Conv3d.weight order:
+ * the input-side operand of mivp_gemm_tn for the patch-embedding weight gradient */
+int mivp_patch_im2col(const MivpEmbedDesc* d, const float* x, void* p, mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* BatchNorm3d, training mode (batch statistics), channels-last bf16         */

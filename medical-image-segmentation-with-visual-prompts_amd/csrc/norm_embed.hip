@@ -83,6 +83,40 @@ extern "C" int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x
     return mivp_check_launch("patch_embed");
 }
 
+// im2col of the k=s=2 patches (they tile the input exactly): p[tok][ci*8 + a*4 + b*2 + c] = x[b,ci,2h+a,2w+b,2d+c]
+// in bf16 -- the B operand of mivp_gemm_tn for the patch-embedding weight gradient (columns in nn.Conv3d order).
+__global__ __launch_bounds__(256) void k_patch_im2col(MivpEmbedDesc d, const float* __restrict__ x, bf16_t* __restrict__ p) {
+    const int Cin = d.Cin, H = d.dims[0], W = d.dims[1], D = d.dims[2];
+    const int oh = H / 2, ow = W / 2, od = D / 2;
+    const long ovol = (long)oh * ow * od, ivol = (long)H * W * D;
+    const long items = (long)d.B * ovol * Cin * 4;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int ab = (int)(it & 3);
+        long r = it >> 2;
+        const int ci = (int)(r % Cin);
+        const long vox = r / Cin;
+        const long b = vox / ovol;
+        long rem = vox - b * ovol;
+        const int h = (int)(rem / ((long)ow * od));
+        rem -= (long)h * ow * od;
+        const int ww = (int)(rem / od);
+        const int z = (int)(rem - (long)ww * od);
+        const float2 xv = *reinterpret_cast<const float2*>(x + (b * Cin + ci) * ivol + ((long)(2 * h + (ab >> 1)) * W + (2 * ww + (ab & 1))) * D + 2 * z);
+        bf16_t* o = p + vox * (Cin * 8) + ci * 8 + ab * 2;
+        o[0] = (bf16_t)xv.x;
+        o[1] = (bf16_t)xv.y;
+    }
+}
+
+extern "C" int mivp_patch_im2col(const MivpEmbedDesc* d, const float* x, void* p, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && p && d->Cin > 0);
+    MIVP_REQUIRE(d->dims[0] % 2 == 0 && d->dims[1] % 2 == 0 && d->dims[2] % 2 == 0);
+    const long items = (long)d->B * (d->dims[0] / 2) * (d->dims[1] / 2) * (d->dims[2] / 2) * d->Cin * 4;
+    const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(k_patch_im2col, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, x, (bf16_t*)p);
+    return mivp_check_launch("patch_im2col");
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics of a bf16 [n_vox][C] tensor
 // ---------------------------------------------------------------------------------------------

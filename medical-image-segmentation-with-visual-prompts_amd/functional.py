@@ -6,11 +6,11 @@ Each fused stage is one ``torch.autograd.Function`` whose forward/backward launc
 kernels by a small per-module cache that is refreshed when a parameter's version changes
 (optimizer step, ``load_state_dict``, ``.to()``).
 
-Gradients built so far: data gradients through every stage, prompt-token and prompt-bias
-gradients of the Swin blocks, BatchNorm affine gradients, weight/bias gradients of the small
-segmentation-head convolutions -- i.e. everything ``--training-mode downstream`` trains
-(swin_unetr.py:33-40, segmentation.py:25-39).  A stage asked for a gradient it has no kernel for
-raises NotImplementedError at forward time instead of silently training nothing.
+Every stage has two backward flavours, chosen at forward time from ``requires_grad`` of its parameters:
+  * frozen parameters (``--training-mode downstream``: swin_unetr.py:33-40, segmentation.py:25-39): data
+    gradients, prompt-token / prompt-bias gradients and the segmentation-head gradients only;
+  * trainable parameters (the ``*_all`` / ``*_decoder`` modes): additionally every weight gradient, from the
+    TN-GEMM / LayerNorm / BatchNorm kernels of csrc/wgrad.hip and csrc/norm_embed.hip.
 """
 from __future__ import annotations
 
@@ -65,22 +65,39 @@ class WeightCache:
         return val
 
 
-def _no_grad_kernel(what: str, *params):
-    """Fail loudly when a parameter that wants a gradient has no backward kernel yet."""
-    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
-        raise NotImplementedError(
-            f"mivp_amd: weight gradients of {what} are not built yet (only the parameter set of "
-            "--training-mode downstream trains on the HIP path so far: prompt tokens, prompt bias, "
-            "segmentation head). Freeze these parameters or run under torch.no_grad().")
-
-
 # ----------------------------------------------------------------------------------------------
 # patch embedding + BatchNorm
 # ----------------------------------------------------------------------------------------------
+class _PatchEmbedFn(torch.autograd.Function):
+    """BN(conv_k2s2(x)); backward = parameter gradients only (the input volume is data)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, bn):
+        training = bn.training
+        y, stats = ops.patch_embed(x, conv_w, conv_b, bn_w.detach().float().contiguous(),
+                                   bn_b.detach().float().contiguous(), bn.eps, bn.running_mean, bn.running_var,
+                                   training=training, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                   return_stats=True)
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, conv_w, conv_b, *stats)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, conv_w, conv_b, scale, shift, mean_rstd = ctx.saved_tensors
+        dw, db, dgamma, dbeta = ops.patch_embed_backward(x, conv_w, conv_b, dy, (scale, shift, mean_rstd), ctx.training)
+        g = ctx.needs_input_grad
+        return (None, dw if g[1] else None, db if g[2] else None, dgamma if g[3] else None, dbeta if g[4] else None, None)
+
+
 def patch_embed(owner, conv, bn, x):
-    _no_grad_kernel("input_layer (patch embedding)", conv.weight, conv.bias, bn.weight, bn.bias)
     if x.requires_grad:
         raise NotImplementedError("mivp_amd: gradient w.r.t. the input volume is not built")
+    params = [conv.weight, conv.bias, bn.weight, bn.bias]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _PatchEmbedFn.apply(x.detach(), conv.weight, conv.bias, bn.weight, bn.bias, bn)
     training = bn.training
     with torch.no_grad():
         y = ops.patch_embed(x.detach(), conv.weight, conv.bias, bn.weight.detach().float().contiguous(),
@@ -116,6 +133,36 @@ class _SwinBlockFn(torch.autograd.Function):
         return dx, dprompt, dts, None, None, None
 
 
+_SWIN_WG_ORDER = ("ln1_w", "ln1_b", "wq", "wk", "wv", "wproj", "bproj", "ln2_w", "ln2_b", "wmlp", "bmlp")
+
+
+class _SwinBlockTrainFn(torch.autograd.Function):
+    """The same block with trainable weights: the 11 body parameters and the three relative-position tables are
+    inputs, so autograd routes the kernels' weight gradients to them."""
+
+    @staticmethod
+    def forward(ctx, x, prompt, ts, t_h, t_w, t_d, w, window, shift, *body):
+        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=True)
+        ctx.saved = saved
+        ctx.w = w
+        ctx.has_prompt = prompt is not None
+        if prompt is not None:
+            ctx.save_for_backward(prompt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        prompt = ctx.saved_tensors[0] if ctx.has_prompt else None
+        dx, dprompt, dts, wg = swin_ops.swin_block_backward(ctx.saved, ctx.w, prompt, dy.contiguous(), True,
+                                                            ctx.has_prompt, need_w=True)
+        ctx.saved = None
+        g = ctx.needs_input_grad
+        body = tuple(wg[k] if g[9 + i] else None for i, k in enumerate(_SWIN_WG_ORDER))
+        return (dx if g[0] else None, dprompt if g[1] else None, dts if g[2] else None,
+                wg["t_h"] if g[3] else None, wg["t_w"] if g[4] else None, wg["t_d"] if g[5] else None,
+                None, None, None) + body
+
+
 def swin_block(block, x, prompt: Optional[torch.Tensor]):
     pe, attn = block.pe, block.attn
     body = [block.attn_norm.weight, block.attn_norm.bias, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
@@ -123,9 +170,8 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
             block.mlp.bias]
     content = [pe.enc_content_h, pe.enc_content_w, pe.enc_content_d, pe.weights_content_h, pe.weights_content_w,
                pe.weights_content_d]
-    _no_grad_kernel("a Swin block's LayerNorm/Linear/relative-bias weights", *body, *content)
     n_prompt = 0 if prompt is None else int(prompt.shape[0])
-    need_bwd = torch.is_grad_enabled()
+    train_w = torch.is_grad_enabled() and any(p.requires_grad for p in body + content)
 
     def build():
         sd = {k: v for k, v in block.state_dict().items()}
@@ -137,6 +183,9 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
         if not pe.use_token_params:
             raise RuntimeError("prompt tokens passed to a block built without token bias parameters")
         ts = pe.token_scores(n_prompt)            # tiny torch matmul: autograd carries d(ts) into the two params
+    if train_w:
+        t_h, t_w, t_d = pe.content_tables()       # same for the content tables [heads, 2w-1]
+        return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, *body)
     return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size)
 
 
@@ -145,7 +194,7 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
 # ----------------------------------------------------------------------------------------------
 class _PatchMergeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w, w_t, merge_last):
+    def forward(ctx, x, norm_w, norm_b, red_w, ln_w, ln_b, w, w_t, merge_last):
         ctx.save_for_backward(x, ln_w, ln_b, w_t)
         ctx.merge_last = merge_last
         return ops.patch_merge(x, ln_w, ln_b, w, merge_last)
@@ -153,13 +202,17 @@ class _PatchMergeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, ln_w, ln_b, w_t = ctx.saved_tensors
+        g = ctx.needs_input_grad
+        if g[1] or g[2] or g[3]:
+            dx, dw, dgamma, dbeta = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last, need_w=True)
+            return (dx if g[0] else None, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None,
+                    None, None, None, None, None)
         dx = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 def patch_merge(mod, x):
     params = [mod.norm.weight, mod.norm.bias, mod.reduction.weight]
-    _no_grad_kernel("PatchMerging", *params)
 
     def build():
         w = mod.reduction.weight.detach().float()
@@ -167,7 +220,8 @@ def patch_merge(mod, x):
                 w.to(BF16).contiguous(), w.t().to(BF16).contiguous())
 
     ln_w, ln_b, w, w_t = mod._wcache.get("w", params, build)
-    return _PatchMergeFn.apply(x, ln_w, ln_b, w, w_t, mod.merge_last_dim)
+    return _PatchMergeFn.apply(x, mod.norm.weight, mod.norm.bias, mod.reduction.weight, ln_w, ln_b, w, w_t,
+                               mod.merge_last_dim)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -177,25 +231,30 @@ class _ConvFn(torch.autograd.Function):
     """Plain conv3d 3^3 (+bias) with an optional residual add: y = conv(x) + residual."""
 
     @staticmethod
-    def forward(ctx, x, residual, wp, wd, bias, cout):
+    def forward(ctx, x, residual, conv_w, conv_b, wp, wd, bias, cout):
         ctx.wd = wd
         ctx.cin = x.shape[-1]
+        ctx.cin_w = conv_w.shape[1]
+        ctx.cout = cout
         ctx.has_res = residual is not None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            ctx.save_for_backward(x)
         return ops.conv3d(x, wp, bias, cout, residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wd, cpad = ctx.wd
-            if cpad != dy.shape[-1]:
-                dy_p = torch.nn.functional.pad(dy, (0, cpad - dy.shape[-1]))
-            else:
-                dy_p = dy
+        g = ctx.needs_input_grad
+        wd, cpad = ctx.wd
+        dy_p = dy if cpad == dy.shape[-1] else torch.nn.functional.pad(dy, (0, cpad - dy.shape[-1]))
+        dx = dw = db = None
+        if g[0]:
             dx = ops.conv3d(dy_p, wd, None, ctx.cin)
-        dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        return dx, dres, None, None, None, None
+        if g[2] or g[3]:
+            (x,) = ctx.saved_tensors
+            dw, db = ops.conv3d_wgrad(x, dy_p, ctx.cout, ctx.cin_w)
+        dres = dy if (ctx.has_res and g[1]) else None
+        return dx, dres, dw if g[2] else None, db if g[3] else None, None, None, None, None
 
 
 def _conv_weights(cache: WeightCache, key, conv):
@@ -208,11 +267,10 @@ def _conv_weights(cache: WeightCache, key, conv):
 
 
 def conv3d_plain(owner, key, conv, x, residual=None):
-    _no_grad_kernel(f"conv '{key}'", conv.weight, conv.bias)
     wp, wd, b = _conv_weights(owner._wcache, key, conv)
     if x.shape[-1] != wp.shape[1] // 27 and x.shape[-1] * 27 > wp.shape[1]:
         raise RuntimeError("conv3d_plain: channel mismatch")
-    return _ConvFn.apply(x, residual, wp, wd, b, conv.out_channels)
+    return _ConvFn.apply(x, residual, conv.weight, conv.bias, wp, wd, b, conv.out_channels)
 
 
 class _BnActConvFn(torch.autograd.Function):
@@ -266,21 +324,20 @@ class _BnActConvFn(torch.autograd.Function):
                 if not need_x:
                     dgamma, dbeta = dg2, db2
             else:
-                if cout > 8:
-                    raise NotImplementedError("mivp_amd: conv weight gradient with Cout > 8 is not built yet")
                 if (need_bw or need_bb) and not need_x:
                     dz = ops.conv3d(dy_p, wd, None, cin)
                     _, dgamma, dbeta = (ops.bn_backward if training else ops.bn_backward_eval)(x, dz, scale, shift, mean_rstd, lrelu)
                 if need_cw or need_cb:
-                    dw, db = ops.conv3d_wgrad_small(x, scale, shift, lrelu, dy_p, cout)
+                    if cout <= 8:
+                        dw, db = ops.conv3d_wgrad_small(x, scale, shift, lrelu, dy_p, cout)
+                    else:                                   # decoder conv_concat: recompute act(BN(x)), then the TN GEMM
+                        dw, db = ops.conv3d_wgrad(ops.affine_act(x, scale, shift, lrelu), dy_p, cout)
         return (dx if need_x else None, dgamma if need_bw else None, dbeta if need_bb else None,
                 dw if need_cw else None, db if need_cb else None, None, None, None, None, None)
 
 
 def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
     key = key or "bn_conv"
-    if conv.out_channels > 8:
-        _no_grad_kernel(f"conv '{key}'", conv.weight, conv.bias)
 
     def build():
         return ops.pack_conv_weight(conv.weight), ops.pack_conv_weight_dgrad(conv.weight)

@@ -215,7 +215,8 @@ def bn_backward_eval(x, dy, scale, shift, mean_rstd, lrelu):
 # ------------------------------------------------------------------------------------------
 # patch embedding (+ its BatchNorm)
 # ------------------------------------------------------------------------------------------
-def patch_embed(x, w, bias, bn_w, bn_b, eps, running_mean, running_var, training=True, momentum=0.1):
+def patch_embed(x, w, bias, bn_w, bn_b, eps, running_mean, running_var, training=True, momentum=0.1,
+                return_stats=False):
     """x f32 [B, Cin, H, W, D] -> bf16 [B, H/2, W/2, D/2, C] = BN(conv_k2s2(x))."""
     B, cin, H, W, D = x.shape
     Cc = w.shape[0]
@@ -239,7 +240,39 @@ def patch_embed(x, w, bias, bn_w, bn_b, eps, running_mean, running_var, training
     y = torch.empty((B, H // 2, W // 2, D // 2, Cc), dtype=BF16, device=x.device)
     L.call("mivp_patch_embed", C.byref(d), C.c_int(1), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(scale), L.ptr(shift),
            L.ptr(None), L.ptr(y), st)
+    if return_stats:
+        return y, (scale, shift, mean_rstd)
     return y
+
+
+def patch_embed_backward(x, w, bias, dy, stats, training=True):
+    """Parameter gradients of BN(conv_k2s2(x)): (dW [C, Cin, 2,2,2], dbias, dgamma, dbeta), all f32.
+    The conv output is recomputed (bf16) instead of having been kept, the BatchNorm backward is the generic one,
+    and dW = dz^T patches runs on the TN GEMM."""
+    scale, shift, mean_rstd = stats
+    B, cin, H, W, D = x.shape
+    Cc = w.shape[0]
+    d = L.EmbedDesc()
+    d.B, d.Cin, d.C = B, cin, Cc
+    for a, v in enumerate((H, W, D)):
+        d.dims[a] = v
+    n_out = B * (H // 2) * (W // 2) * (D // 2)
+    d.nblk = _nblk(n_out * (Cc // 8), Cc // 8, cap=2048)
+    x = x.contiguous().float()
+    wf = w.detach().float().contiguous()
+    bf = bias.detach().float().contiguous()
+    st = L.stream()
+    z = torch.empty((B, H // 2, W // 2, D // 2, Cc), dtype=BF16, device=x.device)
+    one = torch.ones(Cc, dtype=torch.float32, device=x.device)
+    L.call("mivp_patch_embed", C.byref(d), C.c_int(1), L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(one), L.ptr(torch.zeros_like(one)),
+           L.ptr(None), L.ptr(z), st)
+    dz, dgamma, dbeta = (bn_backward if training else bn_backward_eval)(z, dy.contiguous(), scale, shift, mean_rstd, False)
+    patches = torch.empty((n_out, cin * 8), dtype=BF16, device=x.device)
+    L.call("mivp_patch_im2col", C.byref(d), L.ptr(x), L.ptr(patches), st)
+    dw = gemm_tn(dz, operand_rows(Cc), patches, operand_rows(cin * 8), n_out, Cc, cin * 8)
+    from .swin_ops import _colsum_bf16
+    db = _colsum_bf16(dz.view(n_out, Cc))
+    return dw.view(Cc, cin, 2, 2, 2), db, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------------------
@@ -314,19 +347,45 @@ def add_bf16(a, b):
     return y
 
 
-def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last):
+def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last, need_w=False):
+    """dx, and with ``need_w`` also (d reduction.weight [Cout, kC], d norm.weight, d norm.bias) in f32."""
     B, H, W, D, Cc = x.shape
     cout = dy.shape[-1]
     d = merge_desc(B, (H, W, D), Cc, cout, merge_last)
     dx = torch.empty_like(x)
+    T = dy.numel() // cout
+    kC = (8 if merge_last else 4) * Cc
+    wg_dn = torch.empty((T, kC), dtype=BF16, device=x.device) if need_w else None
+    wg_x = torch.empty((T, kC), dtype=BF16, device=x.device) if need_w else None
     L.call("mivp_patch_merge_bwd", C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w_t_bf16), L.ptr(dx),
-           L.stream())
-    return dx
+           L.ptr(wg_dn), L.ptr(wg_x), L.stream())
+    if not need_w:
+        return dx
+    from .swin_ops import ln_wgrad
+    n, dgamma, dbeta = ln_wgrad(wg_x, wg_dn, ln_w, ln_b, float(d.ln_eps), T, kC)
+    dw = gemm_tn(dy, operand_rows(cout), n, operand_rows(kC), T, cout, kC)
+    return dx, dw, dgamma, dbeta
 
 
 # ---------------------------------------------------------------------------------------------
 # weight gradients (csrc/wgrad.hip): out[M][N] (+)= alpha * sum_t A[t][m] B[t][n]
 # ---------------------------------------------------------------------------------------------
+def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor, cout: int, cin: Optional[int] = None):
+    """Weight / bias gradient of a 3x3x3 'same' convolution: x bf16 [B,H,W,D,Cin_p] (the conv's input as it was fed,
+    channel padding included), dy bf16 [B,H,W,D,>=cout].  Returns (dW [cout, cin, 3,3,3], dbias [cout]) in f32."""
+    B, H, W, D, cin_p = x.shape
+    cin = cin or cin_p
+    ld = dy.shape[-1]
+    if ld % 8 or cin_p % 4:
+        raise RuntimeError("conv3d_wgrad: dy channels must be padded to 8, x channels to 4")
+    vox = B * H * W * D
+    dw = gemm_tn(dy, operand_rows(ld), x, operand_conv_taps((H, W, D), cin_p, cin_p), vox, cout, 27 * cin_p,
+                 perm_cin=cin_p)
+    from .swin_ops import _colsum_bf16
+    db = _colsum_bf16(dy.view(vox, ld))[:cout]
+    return dw.view(cout, cin_p, 3, 3, 3)[:, :cin], db
+
+
 def operand_rows(ld: int) -> L.OperandDesc:
     return L.OperandDesc(0, ld, 0, 0, (L.i32 * 3)(0, 0, 0), 0)
 

@@ -111,27 +111,84 @@ def test_downstream_forward_backward(tag):
             assert int(msd[k]) == int(v), k
 
 
-@pytest.mark.parametrize("tag", ["self_supervised_learning_all_e1d0", "supervised_learning_all_e0d0"])
-def test_other_modes_forward_only(tag):
+OTHER = ["self_supervised_learning_all_e1d0", "self_supervised_learning_decoder_e1d1", "supervised_learning_all_e0d0"]
+
+
+@pytest.mark.parametrize("tag", OTHER)
+def test_trainable_backbone_modes_forward_backward(tag):
+    """The *_all / *_decoder modes train the backbone: every requires_grad parameter of the reference's partition
+    gets a gradient from the HIP weight-gradient kernels, compared with autograd over the oracle under the same
+    conditioning-aware rule as the downstream test (see the module docstring)."""
     import mivp_amd
     from mivp_amd.swin_unetr import SwinUnetR
     from oracle.unetr_ref import OracleSwinUnetR
     fx = load_fixture(f"unetr_{tag}")
     conf = Namespace(**fx.meta["conf"])
     sd = round_weights(fx["sd"])
-    want, _ = OracleSwinUnetR(conf, sd)(fx["in"]["x"], training=True)
-    model = SwinUnetR(conf)
-    model.load_state_dict(sd, strict=True)
-    model.to(DEV).train()
-    with torch.no_grad():
-        out = model(fx["in"]["x"].to(DEV))
-    torch.cuda.synchronize()
+    x = fx["in"]["x"]
+    gouts = {"latent_outputs": fx["in"]["gout"]}
+    if "gout_seg" in fx["in"]:
+        gouts["seg_pred"] = fx["in"]["gout_seg"]
+
+    def oracle_run(xx):
+        osd = {k: v.clone() for k, v in sd.items()}
+        for k in fx.meta["trainable"]:
+            osd[k].requires_grad_(True)
+        want, _ = OracleSwinUnetR(conf, osd)(xx, training=True)
+        sum((want[k] * g).sum() for k, g in gouts.items()).backward()
+        return osd, want
+
+    def product_run(xx):
+        model = SwinUnetR(conf)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train()
+        out = model(xx.to(DEV))
+        sum((out[k].float() * g.to(DEV)).sum() for k, g in gouts.items()).backward()
+        torch.cuda.synchronize()
+        return model, out
+
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(1))
+    xp = x * (1 + 2.0 ** -9 * noise)
+    osd, want = oracle_run(x)
+    ysd, _ = oracle_run(xp)
+    model, out = product_run(x)
+    model_p, _ = product_run(xp)
     for k, v in want.items():
         # 16^3 toy volumes: the deepest BatchNorms see 32-256 voxels, which amplifies bf16 noise
-        assert rel_l2(out[k].float().cpu(), v) < 2.5e-2, k
-    # training these modes needs weight-gradient kernels that are not built yet: must fail loudly
-    with pytest.raises(NotImplementedError):
-        model(fx["in"]["x"].to(DEV))
+        assert rel_l2(out[k].float().cpu(), v.detach()) < 2.5e-2, k
+    params = dict(model.named_parameters())
+    params_p = dict(model_p.named_parameters())
+    assert sorted(k for k, q in params.items() if q.requires_grad) == sorted(fx.meta["trainable"])
+    bad = {}
+    import os
+    report = os.environ.get("MIVP_GRAD_REPORT")
+    for k in fx.meta["trainable"]:
+        g, w = params[k].grad, osd[k].grad
+        if w is None:
+            assert g is None or float(g.norm()) == 0.0, k
+            continue
+        assert g is not None, k
+        assert torch.isfinite(g).all(), k
+        # a conv bias in front of a training-mode BatchNorm: the true gradient is zero (a sum of values that cancel
+        # exactly; the oracle shows its own fp32 rounding there); what is left on the HIP side is bf16 rounding of the
+        # summands, small against the same layer's weight gradient
+        sib = osd.get(k.replace(".bias", ".weight")) if k.endswith(".bias") else None
+        scale = float(sib.grad.norm()) if sib is not None and sib.grad is not None else 1.0
+        if float(w.norm()) < 1e-6 or (sib is not None and float(w.norm()) < 1e-4 * scale):
+            assert float(g.norm()) < 2e-2 * max(scale, 1e-3), (k, float(g.norm()), scale)
+            continue
+        g = g.cpu()
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(-1), w.reshape(-1), dim=0))
+        yard = max(rel_l2(ysd[k].grad, w), rel_l2(params_p[k].grad.cpu(), g))
+        e = rel_l2(g, w)
+        if report:
+            print(f"{k:70s} err {e:.3e} cos {cos:.4f} yard {yard:.3e}")
+        # 5 x yardstick here (3 x in the downstream test): these gradients cross the whole network twice, i.e. ~30
+        # bf16 rounding points against the ONE input perturbation the yardstick applies (601 tensors measured:
+        # all cosines > 0.97, three tensors between 3 x and 4 x)
+        if (yard < 0.2 and cos < 0.9) or e > max(5e-2, 5.0 * yard):
+            bad[k] = (e, cos, yard)
+    assert not bad, bad
 
 
 def test_real_channels_forward():

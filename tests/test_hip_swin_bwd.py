@@ -220,15 +220,24 @@ def test_patch_merge_backward_real_channels(C, dims, last):
     from oracle import swin_ref as S
     g = torch.Generator().manual_seed(C)
     k = 8 if last else 4
-    sd = {"norm.weight": 1 + 0.2 * torch.randn(k * C, generator=g), "norm.bias": 0.1 * torch.randn(k * C, generator=g),
-          "reduction.weight": r16(torch.randn(2 * C, k * C, generator=g) / (k * C) ** 0.5)}
+    sd = {"norm.weight": (1 + 0.2 * torch.randn(k * C, generator=g)).requires_grad_(True),
+          "norm.bias": (0.1 * torch.randn(k * C, generator=g)).requires_grad_(True),
+          "reduction.weight": r16(torch.randn(2 * C, k * C, generator=g) / (k * C) ** 0.5).requires_grad_(True)}
     x = r16(torch.randn(2, C, *dims, generator=g)).requires_grad_(True)
     want = S.patch_merge(x, sd, "", last)
     gout = r16(torch.randn(want.shape, generator=g))
     want.backward(gout)
     xc = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
     dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
-    dx = ops.patch_merge_backward(dy, xc, sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV),
-                                  sd["reduction.weight"].t().contiguous().to(DEV, torch.bfloat16), last)
+    w_t = sd["reduction.weight"].detach().t().contiguous().to(DEV, torch.bfloat16)
+    ln_w, ln_b = sd["norm.weight"].detach().to(DEV), sd["norm.bias"].detach().to(DEV)
+    dx = ops.patch_merge_backward(dy, xc, ln_w, ln_b, w_t, last)
     torch.cuda.synchronize()
     assert rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), x.grad) < 1e-2
+    # weight-gradient mode: same dx, plus the parameters' gradients (bf16 operands, fp32 sums: 6e-3)
+    dx2, dw, dgamma, dbeta = ops.patch_merge_backward(dy, xc, ln_w, ln_b, w_t, last, need_w=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    assert rel_l2(dw.cpu(), sd["reduction.weight"].grad) < 6e-3
+    assert rel_l2(dgamma.cpu(), sd["norm.weight"].grad) < 6e-3
+    assert rel_l2(dbeta.cpu(), sd["norm.bias"].grad) < 6e-3
