@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3", "tiny"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg2", "cfg3", "sup_all", "tiny"])
     ap.add_argument("--window", default="7,7,7")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,10 +88,17 @@ def cpu_baseline(conf, size):
     g = torch.Generator().manual_seed(1234)
     nvol = 4 if not (conf.use_encoder_prompting or conf.use_decoder_prompting) else 1     # ~10-30 s of CPU work
     x = torch.rand(nvol, conf.input_channels, size, size, size, generator=g)
-    y = torch.randint(0, conf.output_channels_downstream, (nvol, 1, size, size, size), generator=g).float()
+    mode = conf.training_mode
+    n_cls = conf.output_channels_downstream if mode == "downstream" else conf.output_channels_pretrain
+    y = torch.randint(0, n_cls, (nvol, 1, size, size, size), generator=g).float()
     t0 = time.perf_counter()
     out, _ = model(x, training=True)
-    loss = dice_focal_loss(out["downstream"], y, conf.include_background)
+    if mode == "downstream":                       # same objectives as mivp_amd.train.step_loss
+        loss = dice_focal_loss(out["downstream"], y, conf.include_background)
+    elif mode.startswith("supervised"):
+        loss = dice_focal_loss(out["seg_pred"], y, conf.include_background)
+    else:
+        loss = (out["latent_outputs"] ** 2).mean()
     opt.zero_grad()
     loss.backward()
     opt.step()

@@ -309,7 +309,7 @@ class _BnActConvFn(torch.autograd.Function):
             dy_p = torch.zeros(dy.shape[:-1] + (cpad,), dtype=BF16, device=dy.device)
             dy_p[..., :cout] = dy
         dx = dgamma = dbeta = dw = db = None
-        rows_ok = (not lrelu) and cout <= 5 and cin < 64
+        rows_ok = (not lrelu) and ops.conv3d_wgrad_rows_supported(cin, cout, x.shape[3])
         if need_x:
             dz = ops.conv3d(dy_p, wd, None, cin)            # gradient w.r.t. the conv operand act(BN(x))
             if training:
@@ -327,11 +327,8 @@ class _BnActConvFn(torch.autograd.Function):
                 if (need_bw or need_bb) and not need_x:
                     dz = ops.conv3d(dy_p, wd, None, cin)
                     _, dgamma, dbeta = (ops.bn_backward if training else ops.bn_backward_eval)(x, dz, scale, shift, mean_rstd, lrelu)
-                if need_cw or need_cb:
-                    if cout <= 8:
-                        dw, db = ops.conv3d_wgrad_small(x, scale, shift, lrelu, dy_p, cout)
-                    else:                                   # decoder conv_concat: recompute act(BN(x)), then the TN GEMM
-                        dw, db = ops.conv3d_wgrad(ops.affine_act(x, scale, shift, lrelu), dy_p, cout)
+                if need_cw or need_cb:              # recompute act(BN(x)), then the TN GEMM over voxels
+                    dw, db = ops.conv3d_wgrad(ops.affine_act(x, scale, shift, lrelu), dy_p, cout)
         return (dx if need_x else None, dgamma if need_bw else None, dbeta if need_bb else None,
                 dw if need_cw else None, db if need_cb else None, None, None, None, None, None)
 

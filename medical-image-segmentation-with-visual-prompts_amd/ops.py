@@ -106,6 +106,17 @@ def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
     return dw, out[cout * 27 * cin:].clone()
 
 
+def conv3d_wgrad_rows_supported(cin: int, cout: int, depth: int) -> bool:
+    """Shape window of mivp_conv3d_wgrad_rows (csrc/conv3d.hip: wgrad_rows_cfg + its 160 KiB LDS row images)."""
+    rows, cols = 27 * cout, cin + 1
+    mt = 4 if rows <= 64 else (9 if rows <= 144 else 0)
+    ntc = 1 if cols <= 16 else (2 if cols <= 32 else (4 if cols <= 64 else 0))
+    if not (mt and ntc) or cout > 8:
+        return False
+    dp = (depth + 31) // 32 * 32
+    return 4 * 16 * (mt + ntc) * (dp + 8) * 2 <= 160 * 1024
+
+
 def conv3d_wgrad_rows(x, dy, cout):
     """MFMA weight-gradient core for small-Cout convs: returns (G, S) with
     G[co, tap, ci] = sum_u dy[u - tap][co] * x[u][ci]  (raw x) and S[co, tap] = sum_{u in bounds} dy[u - tap][co]."""

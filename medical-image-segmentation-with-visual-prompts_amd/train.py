@@ -25,6 +25,12 @@ WORKLOADS = {
     # configs[3] (per-GPU shape): both prompt sides, 4-channel 128^3
     "cfg3": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=True,
                  input_channels=4, size=128, batch=1),
+    # configs[0]: the reference's CPU-runnable plumbing case (all parameters train)
+    "cfg0": dict(training_mode="self_supervised_learning_all", use_encoder_prompting=False, use_decoder_prompting=False,
+                 input_channels=1, size=32, batch=2),
+    # every parameter trains on the segmentation objective (students_teacher.py:25-68,190-197), 96^3
+    "sup_all": dict(training_mode="supervised_learning_all", use_encoder_prompting=False, use_decoder_prompting=False,
+                    input_channels=1, size=96, batch=4),
     # smoke-sized
     "tiny": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=True,
                  input_channels=1, size=32, batch=2),
@@ -43,7 +49,9 @@ def make_conf(workload: str, window=(7, 7, 7)) -> Tuple[Namespace, int, int]:
         max_prompts=1, tokens_per_prompt_encoder=64, tokens_per_prompt_decoder=64,
         use_reconstruction=False, use_mutual_learning=False, use_rotation_prediction=False,
         use_contrastive_learning=False, contrastive_coding_dim=512, output_channels_downstream=2,
-        output_channels_pretrain=5, include_background=True, lr_downstream=1e-3, weight_decay_downstream=0.0, **w)
+        output_channels_pretrain=5, include_background=True, lr_downstream=1e-3, weight_decay_downstream=0.0,
+        lr_students_teacher=5e-4, weight_decay_students_teacher=0.1, lr_prompt_tokens=5e-4,
+        weight_decay_prompt_tokens=0.1, **w)
     return conf, size, batch
 
 
@@ -52,7 +60,8 @@ def synthetic_batch(conf: Namespace, batch: int, size: int, device, rank: int = 
     integer masks in [0, out_ch) stored as float like its label volumes (modules/utils.py:372-388)."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(batch, conf.input_channels, size, size, size, generator=g)
-    y = torch.randint(0, conf.output_channels_downstream, (batch, 1, size, size, size), generator=g).float()
+    n_cls = conf.output_channels_downstream if conf.training_mode == "downstream" else conf.output_channels_pretrain
+    y = torch.randint(0, n_cls, (batch, 1, size, size, size), generator=g).float()
     return x.to(device), y.to(device)
 
 
@@ -108,16 +117,51 @@ def dice_focal_loss(logits: torch.Tensor, target: torch.Tensor, include_backgrou
 
 
 def build_optimizer(model, conf: Namespace):
-    """AdamW over ``named_parameters_downstream()`` (segmentation.py:25-39)."""
+    """AdamW over the reference's parameter partition for the mode: ``named_parameters_downstream()`` for
+    ``downstream`` (segmentation.py:25-39); decoder(+encoder) and prompt-token groups with their own lr /
+    weight decay for the ``*_all`` / ``*_decoder`` modes (students_teacher.py:25-68)."""
     core = model.module if hasattr(model, "module") else model
-    params = [p for _, p in core.named_parameters_downstream()]
-    return torch.optim.AdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream),
-                             fused=True)
+    mode = conf.training_mode
+    if mode == "downstream":
+        params = [p for _, p in core.named_parameters_downstream()]
+        return torch.optim.AdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream),
+                                 fused=True)
+    lr, wd = float(conf.lr_students_teacher), float(conf.weight_decay_students_teacher)
+    groups = []
+    if mode in ("self_supervised_learning_all", "supervised_learning_all"):
+        groups.append({"params": [p for _, p in core.named_parameters_decoder()] + [p for _, p in core.named_parameters_encoder()],
+                       "lr": lr, "weight_decay": wd})
+        if conf.use_encoder_prompting:
+            groups.append({"params": [p for _, p in core.named_parameters_prompt_tokens_encoder()],
+                           "lr": float(conf.lr_prompt_tokens), "weight_decay": float(conf.weight_decay_prompt_tokens)})
+    elif mode in ("self_supervised_learning_decoder", "supervised_learning_decoder"):
+        groups.append({"params": [p for _, p in core.named_parameters_decoder()], "lr": lr, "weight_decay": wd})
+    else:
+        raise ValueError(f"no optimizer recipe for training mode {mode!r}")
+    if conf.use_decoder_prompting:
+        groups.append({"params": [p for _, p in core.named_parameters_prompt_tokens_decoder()],
+                       "lr": float(conf.lr_prompt_tokens), "weight_decay": float(conf.weight_decay_prompt_tokens)})
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=wd, fused=True)
+
+
+def step_loss(out: dict, conf: Namespace, y) -> torch.Tensor:
+    """The objective the step differentiates.  ``downstream``: DiceFocal on out['downstream'] (segmentation.py:44-50,
+    104-106).  ``supervised_*``: the segmentation term on out['seg_pred'] (students_teacher.py:190-197; the fused
+    Dice+focal kernel stands in for MONAI's DiceLoss).  ``self_supervised_*``: the reference's ClusteredPrototypeLoss
+    is outside the hot path; a mean-square feature objective on out['latent_outputs'] stands in so that
+    the step exercises the same forward/backward."""
+    mode = conf.training_mode
+    if mode == "downstream":
+        return dice_focal_loss(out["downstream"], y, conf.include_background, 4.0)
+    if mode in ("supervised_learning_all", "supervised_learning_decoder"):
+        return dice_focal_loss(out["seg_pred"], y, conf.include_background, 4.0)
+    lat = out["latent_outputs"]
+    return (lat.float() ** 2).mean()
 
 
 def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
     out = model(x)
-    loss = dice_focal_loss(out["downstream"], y, conf.include_background, 4.0)
+    loss = step_loss(out, conf, y)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()

@@ -60,3 +60,77 @@ def test_gemm_tn_conv_taps(B, dims, cin, cout):
     y = torch.nn.functional.conv3d(x.float().permute(0, 4, 1, 2, 3), w, padding=1)
     y.backward(dy.float().permute(0, 4, 1, 2, 3))
     assert rel_l2(out.view(cout, cin, 3, 3, 3).cpu(), w.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,dims,lrelu", [(24, 16, (6, 6, 8), True), (48, 5, (2, 3, 96), False), (144, 48, (8, 8, 8), True)])
+def test_bn_act_conv_all_parameter_gradients(cin, cout, dims, lrelu):
+    """BatchNorm -> (LeakyReLU) -> conv3x3x3 with every parameter trainable, through the autograd glue: the decoder's
+    conv_concat stage and a 5-class head whose depth (96) is outside the one-pass head kernel's window.
+    Tolerance 6e-3: bf16 operands, fp32 sums (the BatchNorm gradients pass through one more bf16 tensor: 1e-2)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(cin + cout)
+    r16 = lambda t: t.bfloat16().float()
+    x = r16(torch.randn(2, cin, *dims, generator=g) + 0.2).requires_grad_(True)
+    bn = nn.BatchNorm3d(cin)
+    conv = nn.Conv3d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(cin, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(cin, generator=g))
+        conv.weight.copy_(r16(conv.weight))
+    z = bn(x)
+    y = conv(F.leaky_relu(z, 0.01) if lrelu else z)
+    dy = r16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    want = {"x": x.grad, "bn_w": bn.weight.grad, "bn_b": bn.bias.grad, "w": conv.weight.grad, "b": conv.bias.grad}
+
+    class Owner:
+        pass
+    owner = Owner()
+    owner._wcache = Fn.WeightCache()
+    bn2, conv2 = nn.BatchNorm3d(cin).to(DEV), nn.Conv3d(cin, cout, 3, 1, 1).to(DEV)
+    bn2.load_state_dict({k: v for k, v in nn.BatchNorm3d(cin).state_dict().items()})
+    with torch.no_grad():
+        bn2.weight.copy_(bn.weight); bn2.bias.copy_(bn.bias); conv2.weight.copy_(conv.weight); conv2.bias.copy_(conv.bias)
+    xd = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16).requires_grad_(True)
+    out = Fn.bn_act_conv(owner, bn2, conv2, xd, lrelu=lrelu, out_f32=(cout <= 8), key="t")
+    out.backward(dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, out.dtype))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu().permute(0, 4, 1, 2, 3), y.detach()) < 6e-3
+    assert rel_l2(xd.grad.float().cpu().permute(0, 4, 1, 2, 3), want["x"]) < 1e-2
+    assert rel_l2(conv2.weight.grad.cpu(), want["w"]) < 6e-3
+    assert rel_l2(conv2.bias.grad.cpu(), want["b"]) < 6e-3
+    assert rel_l2(bn2.weight.grad.cpu(), want["bn_w"]) < 1e-2
+    assert rel_l2(bn2.bias.grad.cpu(), want["bn_b"]) < 1e-2
+
+
+@pytest.mark.parametrize("cin", [1, 4])
+def test_patch_embed_parameter_gradients(cin):
+    import torch.nn as nn
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(cin)
+    x = torch.rand(2, cin, 12, 8, 10, generator=g)
+    conv, bn = nn.Conv3d(cin, 48, 2, 2), nn.BatchNorm3d(48, eps=1e-6)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(48, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(48, generator=g))
+    y = bn(conv(x))
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    import copy
+    conv2, bn2 = copy.deepcopy(conv).to(DEV), copy.deepcopy(bn).to(DEV)
+    for p in list(conv2.parameters()) + list(bn2.parameters()):
+        p.grad = None
+    bn2.running_mean.zero_(); bn2.running_var.fill_(1.0)
+    out = Fn.patch_embed(None, conv2, bn2, x.to(DEV))
+    out.backward(dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu().permute(0, 4, 1, 2, 3), y.detach()) < 6e-3
+    assert rel_l2(conv2.weight.grad.cpu(), conv.weight.grad) < 6e-3
+    assert rel_l2(bn2.weight.grad.cpu(), bn.weight.grad) < 6e-3
+    assert rel_l2(bn2.bias.grad.cpu(), bn.bias.grad) < 6e-3
+    # the conv bias sits in front of a training-mode BatchNorm: its true gradient is zero
+    assert float(conv2.bias.grad.abs().max()) < 2e-2 * float(conv.weight.grad.abs().max())
