@@ -172,14 +172,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
 }
 
 // out[m][perm(n)] = (accumulate ? out : 0) + alpha * sum_s part[s][m][n];  perm_cin > 0 turns the im2col column
-// order tap*Cin + ci into nn.Conv3d's ci*27 + tap.
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int splits, int M, int N, float alpha,
-                                                        int accumulate, int perm_cin, float* __restrict__ out) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)M * N) return;
+// order tap*Cin + ci into nn.Conv3d's ci*27 + tap.  Block = 32 elements x 32 split-slices (the shape of
+// k_reduce_rows): a slice adds splits slice, slice+32, ... in order, the 32 slice sums meet in a fixed LDS tree.
+__global__ __launch_bounds__(1024) void k_gemm_tn_reduce(const float* __restrict__ part, int splits, int M, int N, float alpha,
+                                                         int accumulate, int perm_cin, float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5, S = blockDim.x >> 5;   // S slices: a power of two <= 32
+    const long total = (long)M * N;
+    const long e = (long)blockIdx.x * 32 + col;
     float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += part[(long)i * M * N + e];
-    s *= alpha;
+    if (e < total)
+        for (int i = slice; i < splits; i += S) s += part[(long)i * total + e];
+    red[slice][col] = s;
+    __syncthreads();
+    for (int h = S >> 1; h > 0; h >>= 1) {
+        if (slice < h) red[slice][col] += red[slice + h][col];
+        __syncthreads();
+    }
+    if (slice != 0 || e >= total) return;
+    s = red[0][col] * alpha;
     long o = e;
     if (perm_cin > 0) {
         const int m = (int)(e / N), n = (int)(e - (long)m * N);
@@ -229,7 +240,9 @@ extern "C" int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* 
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)a, (const bf16_t*)b,
                        (float*)workspace, cps);
     const long total = (long)d->M * d->N;
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    int slices = 1;
+    while (slices < splits && slices < 32) slices *= 2;
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((total + 31) / 32)), dim3(32 * slices), 0, (hipStream_t)stream,
                        (const float*)workspace, splits, d->M, d->N, d->alpha, d->accumulate, d->perm_cin, out);
     return mivp_check_launch("mivp_gemm_tn");
 }
@@ -326,44 +339,39 @@ __global__ __launch_bounds__(256) void k_ln_wgrad(const bf16_t* __restrict__ x, 
 }
 
 // Relative-position-bias table gradients from the window-summed gradient of the K' augmentation columns
-// (mivp_relbias_aug's layout).  dka [heads][Nkp][32] f32.  One thread per table entry walks every (key, column)
-// that read it: deterministic, ~7k terms per entry.
+// (mivp_relbias_aug's layout).  dka [heads][Nkp][32] f32.  One wave per (head, table entry): its lanes stride the
+// keys that read the entry, then a fixed butterfly adds the 64 lane sums (deterministic).
 __global__ __launch_bounds__(64) void k_relbias_grad(MivpSwinDesc d, const float* __restrict__ dka, float* __restrict__ d_th,
                                                      float* __restrict__ d_tw, float* __restrict__ d_td) {
-    const int head = blockIdx.x;
     const int w0 = d.win[0], w1 = d.win[1], w2 = d.win[2];
-    const int n0 = 2 * w0 - 1, n1 = 2 * w1 - 1, n2 = 2 * w2 - 1;
+    const int n0 = 2 * w0 - 1, n1 = 2 * w1 - 1, n2 = 2 * w2 - 1, nall = n0 + n1 + n2;
+    const int head = blockIdx.x / nall, e = blockIdx.x - head * nall;
     const float* g = dka + (long)head * d.Nkp * 32;
-    for (int e = threadIdx.x; e < n0 + n1 + n2; e += 64) {
-        float acc = 0.f;
+    float acc = 0.f;
+    for (int m = threadIdx.x; m < d.Nq; m += 64) {
+        const int k2 = m % w2, k1 = (m / w2) % w1, k0 = m / (w2 * w1);
+        const float* gm = g + m * 32;
         if (e < n0) {
-            for (int m = 0; m < d.Nq; ++m) {
-                const int k0 = m / (w2 * w1);
-                const int a = k0 + w0 - 1 - e;                       // th[k0 - a + w0 - 1] == th[e]
-                if (a >= 0 && a < w0) acc += g[m * 32 + a];
-            }
-            d_th[head * n0 + e] = acc;
+            const int a = k0 + w0 - 1 - e;                           // th[k0 - a + w0 - 1] == th[e]
+            if (a >= 0 && a < w0) acc += gm[a];
         } else if (e < n0 + n1) {
-            const int ee = e - n0;
-            for (int m = 0; m < d.Nq; ++m) {
-                const int k1 = (m / w2) % w1;
-                const int a = k1 + w1 - 1 - ee;
-                if (a >= 0 && a < w1) acc += g[m * 32 + w0 + a];
-            }
-            d_tw[head * n1 + ee] = acc;
+            const int a = k1 + w1 - 1 - (e - n0);
+            if (a >= 0 && a < w1) acc += gm[w0 + a];
         } else {
             const int ee = e - n0 - n1;
-            for (int m = 0; m < d.Nq; ++m) {
-                const int k2 = m % w2;
-                const int a = k2 + w2 - 1 - ee;                      // query i2 = a < w2 - 1 has its own column
-                if (a >= 0 && a < w2 - 1) acc += g[m * 32 + w0 + w1 + a];
-                if (k2 == ee) {                                      // the folded i2 = w2-1 term: + every i0 column, - every i2 column
-                    for (int c = 0; c < w0; ++c) acc += g[m * 32 + c];
-                    for (int c = 0; c < w2 - 1; ++c) acc -= g[m * 32 + w0 + w1 + c];
-                }
+            const int a = k2 + w2 - 1 - ee;                          // query i2 = a < w2 - 1 has its own column
+            if (a >= 0 && a < w2 - 1) acc += gm[w0 + w1 + a];
+            if (k2 == ee) {                                          // the folded i2 = w2-1 term: + every i0 column, - every i2 column
+                for (int c = 0; c < w0; ++c) acc += gm[c];
+                for (int c = 0; c < w2 - 1; ++c) acc -= gm[w0 + w1 + c];
             }
-            d_td[head * n2 + ee] = acc;
         }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) {
+        if (e < n0) d_th[head * n0 + e] = acc;
+        else if (e < n0 + n1) d_tw[head * n1 + (e - n0)] = acc;
+        else d_td[head * n2 + (e - n0 - n1)] = acc;
     }
 }
 
@@ -386,6 +394,7 @@ extern "C" int mivp_ln_wgrad(const void* x, const int32_t* tok_src, const void* 
 extern "C" int mivp_relbias_grad(const MivpSwinDesc* d, const float* dka, float* d_th, float* d_tw, float* d_td,
                                  mivp_stream_t stream) {
     MIVP_REQUIRE(d && dka && d_th && d_tw && d_td && d->augp <= 32);
-    hipLaunchKernelGGL(k_relbias_grad, dim3(d->heads), dim3(64), 0, (hipStream_t)stream, *d, dka, d_th, d_tw, d_td);
+    const int nall = 2 * (d->win[0] + d->win[1] + d->win[2]) - 3;
+    hipLaunchKernelGGL(k_relbias_grad, dim3(d->heads * nall), dim3(64), 0, (hipStream_t)stream, *d, dka, d_th, d_tw, d_td);
     return mivp_check_launch("mivp_relbias_grad");
 }

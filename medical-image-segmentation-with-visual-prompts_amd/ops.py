@@ -390,10 +390,17 @@ def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor, cout: int, cin: Optional[int
     if ld % 8 or cin_p % 4:
         raise RuntimeError("conv3d_wgrad: dy channels must be padded to 8, x channels to 4")
     vox = B * H * W * D
-    dw = gemm_tn(dy, operand_rows(ld), x, operand_conv_taps((H, W, D), cin_p, cin_p), vox, cout, 27 * cin_p,
-                 perm_cin=cin_p)
     from .swin_ops import _colsum_bf16
     db = _colsum_bf16(dy.view(vox, ld))[:cout]
+    if ld <= 16 and cin_p > ld:
+        # few output channels (segmentation heads): let x supply the rows and the shifted dy the columns,
+        #   dW[co][ci][k] = sum_u x[u][ci] * dy[u - (k-1)][co]  =  out[ci][(26 - tap)*ld + co]
+        # so the 64x64 output blocks are full instead of 5/64 occupied
+        out = gemm_tn(x, operand_rows(cin_p), dy, operand_conv_taps((H, W, D), ld, ld), vox, cin_p, 27 * ld)
+        dw = out.view(cin_p, 27, ld)[:, :, :cout].flip(1).permute(2, 0, 1).contiguous()
+        return dw.view(cout, cin_p, 3, 3, 3)[:, :cin], db
+    dw = gemm_tn(dy, operand_rows(ld), x, operand_conv_taps((H, W, D), cin_p, cin_p), vox, cout, 27 * cin_p,
+                 perm_cin=cin_p)
     return dw.view(cout, cin_p, 3, 3, 3)[:, :cin], db
 
 
