@@ -69,6 +69,11 @@ typedef struct MivpSwinDesc {
     int32_t win[3];     /* window size per axis                                */
     float   q_scale;    /* head_dim ** -0.5                                    */
     float   ln_eps;     /* 1e-6                                                */
+    /* dropout of the training forward (window_attention.py:30,33,57,60): an element is dropped when the   */
+    /* 16-bit counter hash of its index under `seed` is below `thr` (= round(p * 65536), 0 = no dropout);   */
+    /* kept elements are scaled by `scale` = 65536 / (65536 - thr).  Backward re-derives the same mask.     */
+    uint32_t attn_drop_thr;   float attn_drop_scale;   uint32_t attn_seed;
+    uint32_t proj_drop_thr;   float proj_drop_scale;   uint32_t proj_seed;
 } MivpSwinDesc;
 
 /* gather + LayerNorm + q/k/v projections  (swin_block.py:205-214, window_attention.py:42-47)
@@ -115,7 +120,9 @@ int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x,
  *   mlp_norm output, dyw [B*P][Nqp][C] bf16 = dy in window order (zero rows where the token was cropped) */
 int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
                            const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
-                           void* d_o, void* d_t1, void* dn_out, void* dyw, mivp_stream_t stream);
+                           void* d_o, void* d_t1, void* dn_out, void* dyw, void* d_pj, mivp_stream_t stream);
+/*   d_pj (NULL unless proj dropout is on in weight-gradient mode): dt1 with the proj-dropout mask applied,
+ *   i.e. the gradient w.r.t. the proj output (A operand of the proj weight gradient) */
 
 /* delta[bp][head][n] = sum_j dO * O  (flash-attention backward row term) */
 int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
@@ -156,6 +163,10 @@ int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, con
 int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const float* dvp, const float* prompt,
                        const float* ln_w, const float* ln_b, const void* wqkv, float* dprompt,
                        void* wg_a, void* wg_n, float* wg_ln, mivp_stream_t stream);
+
+/* test hook: the keep masks the kernels derive from the descriptor's dropout fields, 1 = kept.
+ *   attn_keep u8 [B*P*heads][Nqp][Nkp] (NULL to skip), proj_keep u8 [B*P*Nqp][C] (NULL to skip) */
+int mivp_dropout_masks(const MivpSwinDesc* d, uint8_t* attn_keep, uint8_t* proj_keep, mivp_stream_t stream);
 
 /* out[r] = sum_i in[i][r]  for i < n, r < rows  (deterministic two-level tree) */
 int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream);

@@ -11,14 +11,17 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
 
 class SwinDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "C", "heads", "vol_in", "vol_out", "P", "Nq", "Nqp", "Np", "Npp", "Nkp",
-                                   "aug", "augp", "has_mask")] + [("win", i32 * 3), ("q_scale", f32), ("ln_eps", f32)]
+                                   "aug", "augp", "has_mask")] + [("win", i32 * 3), ("q_scale", f32), ("ln_eps", f32),
+                                                                  ("attn_drop_thr", C.c_uint32), ("attn_drop_scale", f32),
+                                                                  ("attn_seed", C.c_uint32), ("proj_drop_thr", C.c_uint32),
+                                                                  ("proj_drop_scale", f32), ("proj_seed", C.c_uint32)]
 
 
 class MergeDesc(C.Structure):

@@ -61,6 +61,21 @@ MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live) {
     return excl ? -INFINITY : v;
 }
 
+// Counter-based dropout (no RNG state): one 32-bit hash serves the two elements of an index pair, 16 bits each.
+// murmur3's finaliser over (pair index * golden ratio + seed).
+MIVP_DEV uint32_t drop_hash(uint32_t pair_idx, uint32_t seed) {
+    uint32_t h = pair_idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+MIVP_DEV bool drop_keep(uint32_t h, int odd, uint32_t thr) { return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= thr); }
+// pair index of attention element (window-head bph, query q, key k): keys k and k^1 share a hash
+MIVP_DEV uint32_t attn_pair(long bph, int q, int k, int Nqp, int Nkp) {
+    return (uint32_t)((bph * Nqp + q) * (long)(Nkp >> 1) + (k >> 1));
+}
+
 // LDS image of 16-byte-chunked operand rows read as MFMA fragments (lane = (row r, chunk g), ds_read_b128).
 // DK == 32: rows are exactly 64 bytes and the chunk index is XOR-swizzled with {0,3,2,1}[(row >> 2) & 3], which
 // makes every 16-lane service group of ds_read_b128 cover all sixteen 16-byte slots of the 256-byte bank row

@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                            const bf16_t* __restrict__ wmlp_t, const bf16_t* __restrict__ wproj_t,
                                                            bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1,
-                                                           bf16_t* __restrict__ dn_out, bf16_t* __restrict__ dyw) {
-    // dn_out / dyw (optional, weight-gradient mode): gradient w.r.t. the mlp_norm output and dy in window order
+                                                           bf16_t* __restrict__ dn_out, bf16_t* __restrict__ dyw,
+                                                           bf16_t* __restrict__ d_pj) {
+    // dn_out / dyw (optional, weight-gradient mode): gradient w.r.t. the mlp_norm output and dy in window order;
+    // d_pj (optional): dt1 under the proj-dropout mask = gradient w.r.t. the proj output
     constexpr int KS = (CT + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -115,7 +117,17 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rstd * (dh[ct][j] - m1 - tv[ct][j] * m2);
                 out = pack4(v);
-                if (ti.live) st4(d_t1 + ti.tt * (long)C + n0, out);
+                if (ti.live) st4(d_t1 + ti.tt * (long)C + n0, out);      // the residual branch sees dt1 unmasked
+                if (d.proj_drop_thr) {
+                    const uint32_t pi = (uint32_t)((ti.tt * C + n0) >> 1);
+                    const uint32_t h0 = drop_hash(pi, d.proj_seed), h1 = drop_hash(pi + 1, d.proj_seed);
+                    v[0] = drop_keep(h0, 0, d.proj_drop_thr) ? v[0] * d.proj_drop_scale : 0.f;
+                    v[1] = drop_keep(h0, 1, d.proj_drop_thr) ? v[1] * d.proj_drop_scale : 0.f;
+                    v[2] = drop_keep(h1, 0, d.proj_drop_thr) ? v[2] * d.proj_drop_scale : 0.f;
+                    v[3] = drop_keep(h1, 1, d.proj_drop_thr) ? v[3] * d.proj_drop_scale : 0.f;
+                    out = pack4(v);
+                    if (d_pj && ti.live) st4(d_pj + ti.tt * (long)C + n0, out);
+                }
             }
         }
         g1[ct] = out;
@@ -184,7 +196,7 @@ struct AttnBwdGeom {
     static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
 };
 
-template <int DKS, int DVT, int QPW, int NW>
+template <int DKS, int DVT, int QPW, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
@@ -330,6 +342,14 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                         for (int ks = 0; ks < DVS; ++ks)
                             dp = mfma16(*reinterpret_cast<const bf16x8*>(Vimg + (size_t)(16 * lt + r) * VROWB + (32 * ks + 8 * g) * 2), dof[ks], dp);
                     }
+                    if (DROP) {                              // dP = dropout'(dO V^T): same mask and scale as the forward
+                        const uint32_t pi = attn_pair(bph, qrow, 16 * (t0 + lt) + 4 * g, Nqp, Nkp);
+                        const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
+                        dp[0] = drop_keep(h0, 0, d.attn_drop_thr) ? dp[0] * d.attn_drop_scale : 0.f;
+                        dp[1] = drop_keep(h0, 1, d.attn_drop_thr) ? dp[1] * d.attn_drop_scale : 0.f;
+                        dp[2] = drop_keep(h1, 0, d.attn_drop_thr) ? dp[2] * d.attn_drop_scale : 0.f;
+                        dp[3] = drop_keep(h1, 1, d.attn_drop_thr) ? dp[3] * d.attn_drop_scale : 0.f;
+                    }
                     const bool fast = (t0 + lt) < nt_full && !d.has_mask;
                     if (fast) {
 #pragma unroll
@@ -378,8 +398,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 // Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int KPW, int NW, bool AUG>
-__global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
+template <int DKS, int DVT, int KPW, int NW, bool AUG, bool DROP>
+__global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
                                                           const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
@@ -546,8 +566,13 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG) ? 4 : 2) void k_win_att
                         const float sv = classify_logit(s[j], kcls, rqs[j], live);
                         const bool qok = rqs[j] != -1;                      // padding query rows: no P, no gradient
                         const float p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
-                        const float dsv = (live & qok) ? p * (dp[j] - dls[j]) : 0.f;
-                        pv[hh][j] = p;
+                        float keep = 1.f;
+                        if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
+                            const uint32_t hsh = drop_hash(attn_pair(bph, q0 + 16 * lt + 4 * g + j, krow, Nqp, Nkp), d.attn_seed);
+                            keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
+                        }
+                        const float dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
+                        pv[hh][j] = p * keep;
                         ds[hh][j] = dsv;
                         dtok[i] += dsv;
                     }
@@ -812,7 +837,8 @@ static int bwd_checks(const MivpSwinDesc* d) {
 
 extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
                                       const float* ln_w, const float* ln_b, const void* wmlp_t, const void* wproj_t,
-                                      void* d_o, void* d_t1, void* dn_out, void* dyw, mivp_stream_t stream) {
+                                      void* d_o, void* d_t1, void* dn_out, void* dyw, void* d_pj,
+                                      mivp_stream_t stream) {
     int rc = bwd_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(dy && tok_dst && t1 && ln_w && ln_b && wmlp_t && wproj_t && d_o && d_t1);
@@ -822,7 +848,7 @@ extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, con
     hipStream_t st = (hipStream_t)stream;
 #define L_PMB(K) hipLaunchKernelGGL((k_swin_proj_mlp_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, tok_dst, \
                                      (const bf16_t*)t1, ln_w, ln_b, (const bf16_t*)wmlp_t, (const bf16_t*)wproj_t,          \
-                                     (bf16_t*)d_o, (bf16_t*)d_t1, (bf16_t*)dn_out, (bf16_t*)dyw)
+                                     (bf16_t*)d_o, (bf16_t*)d_t1, (bf16_t*)dn_out, (bf16_t*)dyw, (bf16_t*)d_pj)
     CT_SWITCH((d->C + 15) / 16, L_PMB)
 #undef L_PMB
     return mivp_check_launch("swin_proj_mlp_bwd");
@@ -866,7 +892,7 @@ static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const 
     const int nt = d->Nkp / 16;
     const int chunk = pick_chunk(nt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
-    auto kern = k_win_attn_bwd_dq<DKS, DVT, QPW, NW>;
+    auto kern = d->attn_drop_thr ? k_win_attn_bwd_dq<DKS, DVT, QPW, NW, true> : k_win_attn_bwd_dq<DKS, DVT, QPW, NW, false>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, st, *d, chunk, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
@@ -891,7 +917,7 @@ extern "C" int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const 
     return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
 }
 
-template <int DKS, int DVT, int KPW, bool AUG>
+template <int DKS, int DVT, int KPW, bool AUG, bool DROP>
 static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
                       const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
                       const float* delta, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
@@ -908,7 +934,7 @@ static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const
     if (ktiles <= 0) return MIVP_OK;
     constexpr int NW = 8;
     const int ksplit = (ktiles + NW * KPW - 1) / (NW * KPW);
-    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG>;
+    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG, DROP>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
@@ -933,14 +959,16 @@ extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
 #define DKV_ARGS d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, dka_part, st
-    if (dka_part) {
-        if (dks == 1) return launch_dkv<1, 1, 2, true>(DKV_ARGS);
-        if (dks == 2) return launch_dkv<2, 2, 2, true>(DKV_ARGS);
-        return launch_dkv<3, 3, 1, true>(DKV_ARGS);
-    }
-    if (dks == 1) return launch_dkv<1, 1, 2, false>(DKV_ARGS);
-    if (dks == 2) return launch_dkv<2, 2, 2, false>(DKV_ARGS);
-    return launch_dkv<3, 3, 1, false>(DKV_ARGS);
+#define DKV_PICK(AUGV, DROPV)                                              \
+    do {                                                                   \
+        if (dks == 1) return launch_dkv<1, 1, 2, AUGV, DROPV>(DKV_ARGS);   \
+        if (dks == 2) return launch_dkv<2, 2, 2, AUGV, DROPV>(DKV_ARGS);   \
+        return launch_dkv<3, 3, 1, AUGV, DROPV>(DKV_ARGS);                 \
+    } while (0)
+    if (dka_part) { if (d->attn_drop_thr) DKV_PICK(true, true); else DKV_PICK(true, false); }
+    if (d->attn_drop_thr) DKV_PICK(false, true);
+    DKV_PICK(false, false);
+#undef DKV_PICK
 #undef DKV_ARGS
 }
 
@@ -972,6 +1000,36 @@ extern "C" int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const
     hipLaunchKernelGGL(k_prompt_kv_bwd, dim3(d->Np), dim3(256), (2 * d->C + 16) * sizeof(float), (hipStream_t)stream, *d,
                        dkp, dvp, prompt, ln_w, ln_b, (const bf16_t*)wqkv, dprompt, (bf16_t*)wg_a, (bf16_t*)wg_n, wg_ln);
     return mivp_check_launch("prompt_kv_bwd");
+}
+
+// test hook: materialise the keep masks exactly as the kernels derive them
+__global__ __launch_bounds__(256) void k_dropout_masks(MivpSwinDesc d, uint8_t* __restrict__ attn_keep, uint8_t* __restrict__ proj_keep) {
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    if (attn_keep) {
+        const long total = (long)d.B * d.P * d.heads * d.Nqp * d.Nkp;
+        for (long e = gtid; e < total; e += stride) {
+            const int k = (int)(e % d.Nkp);
+            const long rest = e / d.Nkp;
+            const int q = (int)(rest % d.Nqp);
+            const long bph = rest / d.Nqp;
+            const uint32_t h = drop_hash(attn_pair(bph, q, k, d.Nqp, d.Nkp), d.attn_seed);
+            attn_keep[e] = (d.attn_drop_thr == 0 || drop_keep(h, k & 1, d.attn_drop_thr)) ? 1 : 0;
+        }
+    }
+    if (proj_keep) {
+        const long total = (long)d.B * d.P * d.Nqp * d.C;
+        for (long e = gtid; e < total; e += stride) {
+            const uint32_t h = drop_hash((uint32_t)(e >> 1), d.proj_seed);
+            proj_keep[e] = (d.proj_drop_thr == 0 || drop_keep(h, (int)(e & 1), d.proj_drop_thr)) ? 1 : 0;
+        }
+    }
+}
+
+extern "C" int mivp_dropout_masks(const MivpSwinDesc* d, uint8_t* attn_keep, uint8_t* proj_keep, mivp_stream_t stream) {
+    int rc = bwd_checks(d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dropout_masks, dim3(1024), dim3(256), 0, (hipStream_t)stream, *d, attn_keep, proj_keep);
+    return mivp_check_launch("dropout_masks");
 }
 
 extern "C" int mivp_sizeof_desc(int which) {

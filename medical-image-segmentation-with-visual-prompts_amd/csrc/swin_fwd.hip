@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   keeps the kernel under 128 VGPRs so that 16+ waves per CU hide the LDS / MFMA / exp latency
 //   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int NW>
+template <int DKS, int DVT, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
@@ -336,6 +336,18 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(sv[hh][j] - mnew); sv[hh][j] = p; psum += p; }
             lsum = lsum * alpha + psum;
+            if (DROP) {                                      // attention dropout acts on P after the softmax sum
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int key0 = 16 * (2 * u + hh) + 4 * g;
+                    const uint32_t pi = attn_pair(bph, qrow, key0, Nqp, Nkp);
+                    const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
+                    sv[hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[hh][0] : 0.f;
+                    sv[hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[hh][1] : 0.f;
+                    sv[hh][2] = drop_keep(h1, 0, d.attn_drop_thr) ? sv[hh][2] : 0.f;
+                    sv[hh][3] = drop_keep(h1, 1, d.attn_drop_thr) ? sv[hh][3] : 0.f;
+                }
+            }
             const bf16x8 pb = cat44(pack4(sv[0]), pack4(sv[1]));
 #pragma unroll
             for (int dd = 0; dd < DVT; ++dd) {
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
             }
         }
         lsum = col_sum(lsum);
-        const float inv = 1.0f / lsum;
+        const float inv = (DROP ? d.attn_drop_scale : 1.0f) / lsum;
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) {
             const int j0 = 16 * dd + 4 * g;
@@ -409,9 +421,18 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
         if (n0 < C) {
             f32x4 sc = fzero4();
             if (src >= 0) { bf16x4 xv = ld4(x + ((b * d.vol_in + src) * (long)C + n0)); for (int j = 0; j < 4; ++j) sc[j] = (float)xv[j]; }
+            f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+            if (d.proj_drop_thr) {                           // proj dropout: on proj(o) + b, before the residual
+                const uint32_t pi = (uint32_t)((tt * C + n0) >> 1);
+                const uint32_t h0 = drop_hash(pi, d.proj_seed), h1 = drop_hash(pi + 1, d.proj_seed);
+                keep[0] = drop_keep(h0, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
+                keep[1] = drop_keep(h0, 1, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
+                keep[2] = drop_keep(h1, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
+                keep[3] = drop_keep(h1, 1, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float val = (float)(bf16_t)(acc[j] + bproj[n0 + j] + sc[j]);   // t1 lives as bf16
+                const float val = (float)(bf16_t)((acc[j] + bproj[n0 + j]) * keep[j] + sc[j]);   // t1 lives as bf16
                 acc[j] = val;
                 sum += val;
             }
@@ -544,7 +565,7 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
-    auto kern = k_win_attn_fwd<DKS, DVT, NW>;
+    auto kern = d->attn_drop_thr ? k_win_attn_fwd<DKS, DVT, NW, true> : k_win_attn_fwd<DKS, DVT, NW, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }

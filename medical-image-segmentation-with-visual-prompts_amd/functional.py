@@ -113,9 +113,9 @@ def patch_embed(owner, conv, bn, x):
 # ----------------------------------------------------------------------------------------------
 class _SwinBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, prompt, ts, w, window, shift):
+    def forward(ctx, x, prompt, ts, w, window, shift, dropout):
         need = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=need)
+        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=need, dropout=dropout)
         ctx.saved = saved
         ctx.w = w
         ctx.has_prompt = prompt is not None
@@ -130,7 +130,7 @@ class _SwinBlockFn(torch.autograd.Function):
         prompt = ctx.saved_tensors[0] if ctx.has_prompt else None
         dx, dprompt, dts = swin_ops.swin_block_backward(ctx.saved, ctx.w, prompt, dy.contiguous(), need_dx, need_p)
         ctx.saved = None
-        return dx, dprompt, dts, None, None, None
+        return dx, dprompt, dts, None, None, None, None
 
 
 _SWIN_WG_ORDER = ("ln1_w", "ln1_b", "wq", "wk", "wv", "wproj", "bproj", "ln2_w", "ln2_b", "wmlp", "bmlp")
@@ -141,8 +141,8 @@ class _SwinBlockTrainFn(torch.autograd.Function):
     inputs, so autograd routes the kernels' weight gradients to them."""
 
     @staticmethod
-    def forward(ctx, x, prompt, ts, t_h, t_w, t_d, w, window, shift, *body):
-        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=True)
+    def forward(ctx, x, prompt, ts, t_h, t_w, t_d, w, window, shift, dropout, *body):
+        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=True, dropout=dropout)
         ctx.saved = saved
         ctx.w = w
         ctx.has_prompt = prompt is not None
@@ -157,10 +157,10 @@ class _SwinBlockTrainFn(torch.autograd.Function):
                                                             ctx.has_prompt, need_w=True)
         ctx.saved = None
         g = ctx.needs_input_grad
-        body = tuple(wg[k] if g[9 + i] else None for i, k in enumerate(_SWIN_WG_ORDER))
+        body = tuple(wg[k] if g[10 + i] else None for i, k in enumerate(_SWIN_WG_ORDER))
         return (dx if g[0] else None, dprompt if g[1] else None, dts if g[2] else None,
                 wg["t_h"] if g[3] else None, wg["t_w"] if g[4] else None, wg["t_d"] if g[5] else None,
-                None, None, None) + body
+                None, None, None, None) + body
 
 
 def swin_block(block, x, prompt: Optional[torch.Tensor]):
@@ -183,10 +183,18 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
         if not pe.use_token_params:
             raise RuntimeError("prompt tokens passed to a block built without token bias parameters")
         ts = pe.token_scores(n_prompt)            # tiny torch matmul: autograd carries d(ts) into the two params
+    dropout = None
+    p_attn, p_proj = float(attn.attn_drop.p), float(attn.proj_drop.p)
+    if block.training and (p_attn > 0 or p_proj > 0):
+        # counter-hash dropout inside the kernels; the two seeds come from torch's CPU generator, so
+        # torch.manual_seed() reproduces a run (the random STREAM differs from nn.Dropout's by construction)
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,))
+        dropout = (p_attn, p_proj, int(seeds[0]), int(seeds[1]))
     if train_w:
         t_h, t_w, t_d = pe.content_tables()       # same for the content tables [heads, 2w-1]
-        return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, *body)
-    return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size)
+        return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, dropout,
+                                       *body)
+    return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size, dropout)
 
 
 # ----------------------------------------------------------------------------------------------

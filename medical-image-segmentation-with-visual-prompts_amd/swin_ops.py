@@ -97,10 +97,26 @@ class SwinSaved:
     t1: torch.Tensor
 
 
+def set_dropout(d: L.SwinDesc, dropout):
+    """dropout = (p_attn, p_proj, seed_attn, seed_proj) or None: fills the descriptor's counter-hash dropout fields."""
+    if not dropout:
+        return
+    p_attn, p_proj, seed_attn, seed_proj = dropout
+    for name, p, seed in (("attn", p_attn, seed_attn), ("proj", p_proj, seed_proj)):
+        thr = int(round(float(p) * 65536.0))
+        if not 0 <= thr < 65536:
+            raise ValueError("dropout probability must be in [0, 1)")
+        setattr(d, f"{name}_drop_thr", thr)
+        setattr(d, f"{name}_drop_scale", 65536.0 / (65536.0 - thr))
+        setattr(d, f"{name}_seed", int(seed) & 0xFFFFFFFF)
+
+
 def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinBlockWeights,
-                       ts: Optional[torch.Tensor], window, shift_cfg, save: bool = False):
+                       ts: Optional[torch.Tensor], window, shift_cfg, save: bool = False, dropout=None):
     """x: bf16 [B, H, W, D, C] channels-last; prompt: f32 [Np, C] or None; ts: f32 [heads, Np] prompt-token
-    bias scores (``None`` -> ``w.ts``).  Returns y (same shape) and, if ``save``, what backward needs."""
+    bias scores (``None`` -> ``w.ts``); dropout: None or (p_attn, p_proj, seed_attn, seed_proj) for a training
+    forward with ``attn_drop`` / ``proj_drop`` (window_attention.py:57,60).  Returns y (same shape) and, if
+    ``save``, what backward needs (the descriptor carries the dropout seeds to the backward kernels)."""
     if ts is None:
         ts = w.ts
     if ts is not None:
@@ -111,6 +127,7 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     tb = block_tables((H, W_, D), tuple(int(v) for v in window), tuple(int(v) for v in shift_cfg), str(x.device))
     n_prompt = 0 if prompt is None else int(prompt.shape[0])
     d = make_desc(B, Cc, w.heads, tb, n_prompt)
+    set_dropout(d, dropout)
     hd = Cc // w.heads
     dev = x.device
     BP = B * tb.P
@@ -209,8 +226,9 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
     d_t1 = torch.empty_like(d_o)
     dn2 = torch.empty_like(d_o) if need_w else None
     dyw = torch.empty_like(d_o) if need_w else None
+    d_pj = torch.empty_like(d_o) if (need_w and d.proj_drop_thr) else None
     L.call("mivp_swin_proj_mlp_bwd", C.byref(d), L.ptr(dy), L.ptr(tb.tok_dst), L.ptr(sv.t1), L.ptr(w.ln2_w), L.ptr(w.ln2_b),
-           L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), L.ptr(dn2), L.ptr(dyw), st)
+           L.ptr(w.wmlp_t), L.ptr(w.wproj_t), L.ptr(d_o), L.ptr(d_t1), L.ptr(dn2), L.ptr(dyw), L.ptr(d_pj), st)
     wg = None
     if need_w:
         wg = {}
@@ -218,9 +236,10 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
         n2, wg["ln2_w"], wg["ln2_b"] = ln_wgrad(sv.t1, dn2, w.ln2_w, w.ln2_b, d.ln_eps, T, Cc)
         wg["wmlp"] = ops.gemm_tn(dyw, rows, n2, rows, T, Cc, Cc)
         wg["bmlp"] = _colsum_bf16(dyw.view(T, Cc))
-        wg["wproj"] = ops.gemm_tn(d_t1, rows, sv.o, rows, T, Cc, Cc)
-        wg["bproj"] = _colsum_bf16(d_t1.view(T, Cc))
-        del n2, dn2, dyw
+        g_pj = d_pj if d_pj is not None else d_t1          # gradient w.r.t. the proj output
+        wg["wproj"] = ops.gemm_tn(g_pj, rows, sv.o, rows, T, Cc, Cc)
+        wg["bproj"] = _colsum_bf16(g_pj.view(T, Cc))
+        del n2, dn2, dyw, d_pj
     delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
     dx = dprompt = dts = None
     dk = dv = None

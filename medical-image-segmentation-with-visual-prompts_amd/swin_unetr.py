@@ -118,9 +118,6 @@ class SwinTransformerBlock(nn.Module):
     def forward(self, x, p=None):
         """x: bf16 channels-last [B,H,W,D,C]; p: [Np, C] prompt parameter (or the reference's
         batch-broadcast [B,Np,C], of which row 0 is used -- all rows are identical)."""
-        if self.training and (self.attn.attn_drop.p > 0 or self.attn.proj_drop.p > 0):
-            raise NotImplementedError("mivp_amd: dropout inside the fused Swin kernels is not built yet; "
-                                      "run with attn_drop = proj_drop = 0")
         if p is not None and p.dim() == 3:
             p = p[0]
         return Fn.swin_block(self, x, p)

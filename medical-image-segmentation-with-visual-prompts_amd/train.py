@@ -37,15 +37,17 @@ WORKLOADS = {
 }
 
 
-def make_conf(workload: str, window=(7, 7, 7)) -> Tuple[Namespace, int, int]:
-    """yml defaults of configurations/example_configs.yml with dropout off (the fused kernels have no
-    dropout yet) and the north star's 7x7x7 window; returns (conf, volume size, per-GPU batch)."""
+def make_conf(workload: str, window=(7, 7, 7), dropout: float = 0.0) -> Tuple[Namespace, int, int]:
+    """yml defaults of configurations/example_configs.yml with the north star's 7x7x7 window; ``dropout`` sets
+    attn_drop = proj_drop (0 for parity runs, the yml's 0.1 for throughput: SURVEY 8d); returns
+    (conf, volume size, per-GPU batch)."""
     w = dict(WORKLOADS[workload])
     size, batch = w.pop("size"), w.pop("batch")
     conf = Namespace(
         depth_unet=3, hidden_channels=[48, 96, 192, 384], input_patch_size=[2, 2, 2], unetr_res_block="none",
         unetr_up_block="swin", basic_block_res=True, num_heads_encoder=4, num_heads_decoder=4,
-        attn_window_size=list(window), pos_bias_embed_dim=64, use_checkpoint=False, attn_drop=0.0, proj_drop=0.0,
+        attn_window_size=list(window), pos_bias_embed_dim=64, use_checkpoint=False, attn_drop=float(dropout),
+        proj_drop=float(dropout),
         max_prompts=1, tokens_per_prompt_encoder=64, tokens_per_prompt_decoder=64,
         use_reconstruction=False, use_mutual_learning=False, use_rotation_prediction=False,
         use_contrastive_learning=False, contrastive_coding_dim=512, output_channels_downstream=2,

@@ -169,7 +169,8 @@ def shift_mask(geo: BlockGeometry) -> Optional[Tensor]:
 # attention  (a10)
 # ----------------------------------------------------------------------------
 def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
-                     bias: Optional[Tensor], mask: Optional[Tensor], n_query: int) -> Tensor:
+                     bias: Optional[Tensor], mask: Optional[Tensor], n_query: int,
+                     attn_keep: Optional[Tensor] = None, proj_keep: Optional[Tensor] = None) -> Tensor:
     """Windowed MHSA on normalised tokens ``y [B, P, Nk, C]``; returns the
     projected output for the first ``n_query`` rows ``[B, P, n_query, C]``.
 
@@ -178,6 +179,10 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
     ``bias`` is ``[heads, n_query, Nk]``, ``mask`` ``[P, n_query, Nk]`` (1 = keep,
     0 = logit forced to 0).  Prompt rows are keys/values only, so their query
     rows (discarded by the block, swin_block.py:223-225) are never formed here.
+
+    Training-mode dropout (window_attention.py:33,57,60) is stated with EXPLICIT masks so a test can
+    hand over the very mask another implementation drew: ``attn_keep [B,P,heads,n_query,Nk]`` and
+    ``proj_keep [B,P,n_query,C]`` hold 0 or 1/(1-p), i.e. ``nn.Dropout``'s multiplier.
     """
     B, P, Nk, C = y.shape
     hd = C // heads
@@ -195,8 +200,13 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
     if mask is not None:
         logits = logits * mask[None, :, None]
     prob = logits.softmax(dim=-1)
+    if attn_keep is not None:
+        prob = prob * attn_keep
     o = (prob @ v).permute(0, 1, 3, 2, 4).reshape(B, P, n_query, C)
-    return F.linear(o, sd[f"{prefix}attn.proj.weight"], sd[f"{prefix}attn.proj.bias"])
+    out = F.linear(o, sd[f"{prefix}attn.proj.weight"], sd[f"{prefix}attn.proj.bias"])
+    if proj_keep is not None:
+        out = out * proj_keep
+    return out
 
 
 # ----------------------------------------------------------------------------
@@ -204,8 +214,10 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
 # ----------------------------------------------------------------------------
 def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefix: str,
                window: Sequence[int], shift_cfg: Sequence[int], heads: int,
-               embed_dim: int = 64) -> Tensor:
-    """One SwinTransformerBlock (dropout 0), ``x [B,C,H,W,D]`` -> same shape.
+               embed_dim: int = 64, attn_keep: Optional[Tensor] = None,
+               proj_keep: Optional[Tensor] = None) -> Tensor:
+    """One SwinTransformerBlock, ``x [B,C,H,W,D]`` -> same shape (dropout only through the explicit
+    multiplier masks of ``window_attention``).
 
     Follows swin_block.py:145-255.  ``prompt``
     is ``[Np, C]`` (the reference broadcasts the same tokens to every batch
@@ -230,7 +242,7 @@ def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefi
     mask = shift_mask(geo)
     if mask is not None and n_prompt:
         mask = torch.cat([mask, mask.new_ones(geo.P, geo.N, n_prompt)], dim=2)   # :189-196
-    t1 = window_attention(y, sd, prefix, heads, bias, mask, geo.N) + tok
+    t1 = window_attention(y, sd, prefix, heads, bias, mask, geo.N, attn_keep, proj_keep) + tok
     t2 = t1 + F.linear(F.layer_norm(t1, (C,), sd[f"{prefix}mlp_norm.weight"], sd[f"{prefix}mlp_norm.bias"], 1e-6),
                        sd[f"{prefix}mlp.weight"], sd[f"{prefix}mlp.bias"])
     out = x.new_zeros(B, geo.padded[0] * geo.padded[1] * geo.padded[2], C)

@@ -278,6 +278,40 @@ def test_training_step_is_bitwise_reproducible(workload):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+def test_dropout_training_mode_end_to_end():
+    """yml default attn_drop = proj_drop = 0.1: a training forward/backward runs, is reproducible under
+    torch.manual_seed, changes with the seed, and eval mode ignores dropout."""
+    import mivp_amd
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, size, batch = train.make_conf("tiny", dropout=0.1)
+    torch.manual_seed(0)
+    model = SwinUnetR(conf).to(DEV).train()
+    x, y = train.synthetic_batch(conf, batch, size, DEV)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        out = model(x)["downstream"]
+        loss = train.dice_focal_loss(out, y, True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    o1, g1 = run(7)
+    o2, g2 = run(7)
+    o3, _ = run(8)
+    assert torch.equal(o1, o2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    assert not torch.equal(o1, o3)
+    assert all(torch.isfinite(v).all() for v in g1.values()) and len(g1) > 0
+    conf0, _, _ = train.make_conf("tiny", dropout=0.0)
+    ref = SwinUnetR(conf0).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        assert torch.equal(model(x)["downstream"], ref(x)["downstream"])
+
+
 def test_single_rank_ddp_step_on_rccl():
     """One-process 'nccl' (RCCL) group: DistributedDataParallel wraps the HIP model, a training step runs and the
     gradients equal the un-wrapped model's (the multi-rank reduction itself is covered by the gloo CPU test)."""

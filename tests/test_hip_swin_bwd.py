@@ -193,6 +193,66 @@ def test_block_weight_gradients_real_sizes(window, dims, C, heads, n_prompt, shi
         assert err < 1.5e-2, (k, err)
 
 
+@pytest.mark.parametrize("tag,p_attn,p_proj", [("oddpad_shift_prompt", 0.1, 0.1), ("nopad_shift", 0.25, 0.0),
+                                               ("w442_shift_prompt", 0.0, 0.3)])
+def test_block_dropout_matches_oracle_under_the_same_masks(tag, p_attn, p_proj):
+    """attn_drop / proj_drop (window_attention.py:57,60): the kernels draw their masks from a counter hash, so the
+    random stream cannot equal nn.Dropout's; instead the masks the kernels used are exported through
+    mivp_dropout_masks and handed to the oracle, after which forward, dx, prompt and weight gradients must agree as
+    in the dropout-free tests.  The drop rate itself is checked against p."""
+    import ctypes as C
+    import mivp_amd
+    from mivp_amd import swin_ops, _lib as L
+    from oracle import swin_ref as S
+    fx = load_fixture(f"block_{tag}")
+    m = fx.meta
+    window, shift, heads = m["window"], m["shift"], m["heads"]
+    sd = _rounded_state(fx["sd"])
+    x, prm, gout = r16(fx["in"]["x"]), fx["in"].get("prompt"), r16(fx["in"]["gout"])
+    n_prompt = 0 if prm is None else prm.shape[0]
+    w = swin_ops.weights_from_state(sd, "", heads, 64, 0, torch.device(DEV), need_bwd=True)
+    ts = None
+    if n_prompt:
+        ts = ((sd["pe.weights_token"] @ sd["pe.enc_token.0"].t())[:, :n_prompt] * (64 ** -0.5)).to(DEV)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = None if prm is None else prm.to(DEV)
+    y, saved = swin_ops.swin_block_forward(xc, pd, w, ts, window, shift, save=True, dropout=(p_attn, p_proj, 1234, 987))
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dx, dprompt, dts, wg = swin_ops.swin_block_backward(saved, w, pd, dy, True, n_prompt > 0, need_w=True)
+    d = saved.desc
+    B, P, Nq, Nqp, Nkp, Cc = d.B, d.P, d.Nq, d.Nqp, d.Nkp, d.C
+    ak = torch.empty((B * P * heads, Nqp, Nkp), dtype=torch.uint8, device=DEV)
+    pk = torch.empty((B * P * Nqp, Cc), dtype=torch.uint8, device=DEV)
+    L.call("mivp_dropout_masks", C.byref(d), L.ptr(ak), L.ptr(pk), L.stream())
+    torch.cuda.synchronize()
+    ak = ak.cpu().view(B, P, heads, Nqp, Nkp).float()
+    cols = list(range(Nq)) + list(range(Nqp, Nqp + n_prompt))            # oracle key order: window slots, then prompts
+    attn_keep = ak[:, :, :, :Nq][..., cols] * float(d.attn_drop_scale)
+    proj_keep = pk.cpu().view(B, P, Nqp, Cc)[:, :, :Nq].float() * float(d.proj_drop_scale)
+    if p_attn:
+        assert abs(1.0 - float(ak.mean()) - p_attn) < 0.02
+    if p_proj:
+        assert abs(1.0 - float(pk.float().mean()) - p_proj) < 0.03
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.is_floating_point() and "pe." not in k:
+            v.requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    po = prm.clone().requires_grad_(True) if prm is not None else None
+    want = S.swin_block(xo, po, sdo, "", window, shift, heads, 64, attn_keep if p_attn else None,
+                        proj_keep if p_proj else None)
+    want.backward(gout)
+    assert rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), want.detach()) < 6e-3
+    assert rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), xo.grad) < 1.5e-2
+    if n_prompt:
+        assert rel_l2(dprompt.cpu(), po.grad) < 1.5e-2
+    for short, key in WEIGHT_KEYS.items():
+        assert rel_l2(wg[short].cpu().reshape(sdo[key].shape), sdo[key].grad) < 1.5e-2, key
+    # without the masks the oracle must NOT agree (the test would be vacuous if dropout were a no-op)
+    plain = S.swin_block(x, prm, sd, "", window, shift, heads)
+    assert rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), plain) > 2e-2
+
+
 @pytest.mark.parametrize("tag", ["even_T", "odd_T", "even_F", "odd_F"])
 def test_patch_merge_backward_golden(tag):
     import mivp_amd
