@@ -144,7 +144,8 @@ def main():
     # this pool (clock ramp from the low-power state, allocator growth); measured with tools/cpu_bound_check.py
     t_settle = time.perf_counter()
     n_settle = 0
-    while n_settle < 10 or (time.perf_counter() - t_settle < args.settle and n_settle < 200):
+    # under DDP every rank must run the same number of steps (each one is a collective): fixed count there
+    while (n_settle < 30) if world > 1 else (n_settle < 10 or (time.perf_counter() - t_settle < args.settle and n_settle < 200)):
         train.train_step(net, opt, conf, x, y)
         n_settle += 1
         if n_settle % 10 == 0:

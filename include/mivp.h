@@ -234,11 +234,13 @@ int mivp_conv3d_wgrad_small(const MivpConvDesc* d, const void* x, const float* s
                             const void* dy, int32_t dy_stride, float* part, float* dwdb,
                             mivp_stream_t stream);
 
-/* MFMA form of the same gradient (what the product uses): gs [16*MT][16*NTC] f32 row-major with
- *   gs[co*27 + tap][c]   = sum_u dy[u - tap][co] * x[u][c]          (raw x, no affine)   for c < Cin
- *   gs[co*27 + tap][Cin] = sum_{u in bounds} dy[u - tap][co]
- * (MT = 4 if 27*Cout <= 64 else 9 ; NTC = 1, 2 or 4 covering Cin+1 columns).  The conv weight gradient,
- * its bias gradient and the gradients of a BatchNorm fused in front of the conv are linear functions of gs. */
+/* MFMA form of the same gradient (what the product uses): gs [3][80][64] f32 with, for the tap
+ * (sh, sw, sd) in {-1,0,1}^3, nb = (sh+1)*3 + (sw+1):
+ *   gs[sd+1][nb*8 + co][c]   = sum_u dy[u - tap][co] * x[u][c]          (raw x, no affine)   for c < Cin
+ *   gs[sd+1][nb*8 + co][Cin] = sum_{u in bounds} dy[u - tap][co]
+ * dy carries 8 channels (dy_stride == 8, zero padded), Cout <= 8, Cin % 8 == 0, Cin < 64.  The conv weight
+ * gradient, its bias gradient and the gradients of a BatchNorm fused in front of the conv are linear
+ * functions of gs.  `_ws` = number of f32 partial values the call needs in `part`. */
 size_t mivp_conv3d_wgrad_rows_ws(const MivpConvDesc* d);
 int mivp_conv3d_wgrad_rows(const MivpConvDesc* d, const void* x, const void* dy, int32_t dy_stride,
                            float* part, float* gs, mivp_stream_t stream);

@@ -439,155 +439,134 @@ extern "C" int mivp_conv3d_wgrad_small(const MivpConvDesc* d, const void* x, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// small-Cout weight gradient on MFMA ("rows" formulation).
-//   G[(co,tap)][c] = sum_u dy[u - tap][co] * x[u][c]         (u over all voxels, dy zero outside)
-//   column Cin of G accumulates S[(co,tap)] = sum_{u in bounds} dy[u - tap][co]  (x extended by a 1)
-// A wave owns one (b,h,w) row of D voxels at a time: the row of x is staged TRANSPOSED in LDS
-// (xT[c][d]) and the nine neighbouring dy rows are staged transposed and pre-shifted along d
-// (DT[(co,tap)][d]), so both MFMA operands are 16-byte aligned K-major reads (K = voxels).
-// G and S are linear in the raw x: the BatchNorm affine in front of the conv, the conv weight
-// gradient, dgamma and dbeta all follow from (G, S) by O(27*Cout*Cin) algebra on the host.
+// small-Cout weight gradient on MFMA ("rows" formulation), K = the D voxels of one (b,h,w) row.
+//   G[sd][nb*8 + co][c] = sum_d' dy[(h-sh, w-sw, d')][co] * x[(h, w, d'+sd)][c]      nb = (sh+1)*3 + (sw+1)
+//   i.e. the tap (sh, sw, sd) entry of  sum_u dy[u - tap][co] * x[u][c];  column c = Cin carries a 1 for
+//   in-range voxels and so accumulates S = sum_{u in bounds} dy[u - tap][co].
+// A workgroup owns one row at a time.  Both operands are staged ROW-major (d outermost) with 16-byte writes:
+//   A image [d][9 neighbour rows x 8 dy channels]   B image [d + halo][x channels | 1 | 0]
+// and read back through ds_read_b64_tr_b16 (K innermost); the three d-shifts of a tap triple are just the B
+// fragment read one row up / down.  Wave w owns x-channel tile w: 3 shifts x 5 row tiles of accumulators.
+// G and S are linear in the raw x: the BatchNorm affine in front of the conv, the conv weight gradient, dgamma
+// and dbeta all follow from (G, S) by O(27*Cout*Cin) algebra on the host.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NTC>
+typedef __attribute__((address_space(3))) bf16x4 wr_lds_bf16x4;
+MIVP_DEV bf16x4 wr_tr_read(const char* smem, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wr_lds_bf16x4*)(smem + byte_off));
+}
+// blocks of 4 rows x 16 columns (128 B); S blocks per 4-row group, column block XOR-ed with bit 3 of the row so that
+// the two 16-lane groups of a half (8 rows apart) fall into opposite halves of the 256-byte bank row
+template <int S>
+MIVP_DEV int wr_off(int row, int col) {
+    return (((row >> 2) * S + ((col >> 4) ^ ((row >> 3) & 1))) << 7) + ((row & 3) << 5) + ((col & 15) << 1);
+}
+constexpr int WR_AS = 6, WR_BS = 4, WR_MT = 5;
+
 __global__ __launch_bounds__(256) void k_conv3d_wgrad_rows(MivpConvDesc d, const bf16_t* __restrict__ x,
-                                                           const bf16_t* __restrict__ dy, int dy_stride,
-                                                           float* __restrict__ part) {
+                                                           const bf16_t* __restrict__ dy, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin, Cout = d.Cout;
-    const int Dp = (D + 31) / 32 * 32;
-    const int ROW = (Dp + 8) * 2;
-    char* xT = smem + (size_t)wave * (16 * (MT + NTC)) * ROW;
-    char* DT = xT + (size_t)(16 * NTC) * ROW;
+    const int r = lane & 15, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
+    const int Dp = (D + 31) / 32 * 32, G8 = Cin / 8;
+    char* Aimg = smem;                                            // rows 0 .. Dp-1
+    char* Bimg = smem + (size_t)(Dp / 4) * WR_AS * 128;           // rows 0 .. Dp+7  (row = d + 4)
     const long rows_total = (long)d.B * H * W;
-    const long waves_total = (long)gridDim.x * 4;
-    const long wid = (long)blockIdx.x * 4 + wave;
-    const long trips = (rows_total + waves_total - 1) / waves_total;
-    const int G8 = Cin / 8;
+    const bool wave_on = 16 * wave < Cin + 1;
 
-    f32x4 acc[MT][NTC];
+    f32x4 acc[3][WR_MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int sd = 0; sd < 3; ++sd)
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = fzero4();
+        for (int mt = 0; mt < WR_MT; ++mt) acc[sd][mt] = fzero4();
 
-    for (long it = 0; it < trips; ++it) {
-        const long row = wid + it * waves_total;
-        const bool live = row < rows_total;
-        __syncthreads();                                   // previous trip's reads are done
-        if (live) {
-            const long b = row / ((long)H * W);
-            const int h = (int)((row / W) % H), w = (int)(row % W);
-            // zero both images (pad columns, missing neighbours, shifted-out ends)
-            for (int e = lane; e < (16 * (MT + NTC)) * ROW / 16; e += 64) *reinterpret_cast<bf16x8*>(xT + 16 * e) = zero8();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            // x row, transposed; extra channel Cin = 1 for in-bounds voxels
-            const bf16_t* xrow = x + ((b * H + h) * (long)W + w) * D * Cin;
-            for (int e = lane; e < D * G8; e += 64) {
-                const int dd = e / G8, cg = e - dd * G8;
-                const bf16x8 v = ld8(xrow + (long)dd * Cin + cg * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(xT + (size_t)(cg * 8 + j) * ROW + 2 * dd) = v[j];
+    for (long row = blockIdx.x; row < rows_total; row += gridDim.x) {
+        const long b = row / ((long)H * W);
+        const int h = (int)((row / W) % H), w = (int)(row % W);
+        __syncthreads();                                          // previous row's reads are done
+        for (int e = tid; e < 10 * Dp; e += 256) {                // A: 9 neighbour dy rows (+ one zero piece) per d
+            const int dd = e / 10, pc = e - dd * 10;
+            bf16x8 v = zero8();
+            if (pc < 9 && dd < D) {
+                const int hh = h - (pc / 3 - 1), ww = w - (pc % 3 - 1);
+                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+                    v = ld8(dy + (((b * H + hh) * (long)W + ww) * D + dd) * 8);
             }
-            for (int dd = lane; dd < D; dd += 64) *reinterpret_cast<bf16_t*>(xT + (size_t)Cin * ROW + 2 * dd) = (bf16_t)1.0f;
-            // nine neighbouring dy rows, transposed and shifted:  DT[co*27 + tap][dz + sd] = dy[(h-sh, w-sw, dz)][co]
-            for (int nb = 0; nb < 9; ++nb) {
-                const int sh = nb / 3 - 1, sw = nb % 3 - 1;
-                const int hh = h - sh, ww = w - sw;
-                if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-                const bf16_t* drow = dy + ((b * H + hh) * (long)W + ww) * D * dy_stride;
-                for (int dz = lane; dz < D; dz += 64) {
-                    bf16_t vals[8];
-                    if (dy_stride == 8) { const bf16x8 v = ld8(drow + (long)dz * 8); for (int j = 0; j < 8; ++j) vals[j] = v[j]; }
-                    else { for (int j = 0; j < 8; ++j) vals[j] = j < Cout ? drow[(long)dz * dy_stride + j] : (bf16_t)0.0f; }
-#pragma unroll
-                    for (int co = 0; co < 8; ++co) {
-                        if (co < Cout) {
-#pragma unroll
-                            for (int sd = -1; sd <= 1; ++sd) {
-                                const int dt = dz + sd;
-                                if (dt >= 0 && dt < D) {
-                                    const int tap = (nb / 3) * 9 + (nb % 3) * 3 + (sd + 1);
-                                    *reinterpret_cast<bf16_t*>(DT + (size_t)(co * 27 + tap) * ROW + 2 * dt) = vals[co];
-                                }
-                            }
-                        }
-                    }
-                }
+            *reinterpret_cast<bf16x8*>(Aimg + wr_off<WR_AS>(dd, pc * 8)) = v;
+        }
+        const bf16_t* xrow = x + ((b * H + h) * (long)W + w) * D * Cin;
+        for (int e = tid; e < 8 * (Dp + 8); e += 256) {           // B: x row with a 4-row halo, the ones column, zeros
+            const int rr = e >> 3, pc = e & 7, dd = rr - 4;
+            bf16x8 v = zero8();
+            if (dd >= 0 && dd < D) {
+                if (pc < G8) v = ld8(xrow + (long)dd * Cin + pc * 8);
+                else if (pc == G8) v[0] = (bf16_t)1.0f;
             }
+            *reinterpret_cast<bf16x8*>(Bimg + wr_off<WR_BS>(rr, pc * 8)) = v;
         }
         __syncthreads();
-        if (live) {
+        if (wave_on) {
             for (int ks = 0; ks < Dp / 32; ++ks) {
-                bf16x8 bfr[NTC];
+                const int r0 = 32 * ks + 8 * g + q;
+                bf16x8 bf[3];
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt) bfr[nt] = *reinterpret_cast<const bf16x8*>(xT + (size_t)(16 * nt + r) * ROW + (32 * ks + 8 * g) * 2);
+                for (int sd = 0; sd < 3; ++sd) {
+                    const int rb = r0 + 4 + (sd - 1);
+                    bf[sd] = cat44(wr_tr_read(Bimg, wr_off<WR_BS>(rb, 16 * wave + 4 * pp)),
+                                   wr_tr_read(Bimg, wr_off<WR_BS>(rb + 4, 16 * wave + 4 * pp)));
+                }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(DT + (size_t)(16 * mt + r) * ROW + (32 * ks + 8 * g) * 2);
+                for (int mt = 0; mt < WR_MT; ++mt) {
+                    const bf16x8 a = cat44(wr_tr_read(Aimg, wr_off<WR_AS>(r0, 16 * mt + 4 * pp)),
+                                           wr_tr_read(Aimg, wr_off<WR_AS>(r0 + 4, 16 * mt + 4 * pp)));
 #pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = mfma16(a, bfr[nt], acc[mt][nt]);
+                    for (int sd = 0; sd < 3; ++sd) acc[sd][mt] = mfma16(a, bf[sd], acc[sd][mt]);
                 }
             }
         }
     }
-    // partial [wave][16*MT][16*NTC]
-    float* my = part + wid * (long)(16 * MT) * (16 * NTC);
+    // partial [block][3][80][64]
+    float* my = part + (long)blockIdx.x * 3 * 80 * 64;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int sd = 0; sd < 3; ++sd)
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt)
+        for (int mt = 0; mt < WR_MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) my[(long)(16 * mt + 4 * g + j) * (16 * NTC) + 16 * nt + r] = acc[mt][nt][j];
-}
-
-static int wgrad_rows_cfg(const MivpConvDesc* d, int* mt, int* ntc) {
-    const int rows = 27 * d->Cout, cols = d->Cin + 1;
-    *mt = rows <= 64 ? 4 : (rows <= 144 ? 9 : 0);
-    *ntc = cols <= 16 ? 1 : (cols <= 32 ? 2 : (cols <= 64 ? 4 : 0));
-    return (*mt && *ntc) ? MIVP_OK : MIVP_EUNSUPPORTED;
+            for (int j = 0; j < 4; ++j) my[((long)sd * 80 + 16 * mt + 4 * g + j) * 64 + 16 * wave + r] = acc[sd][mt][j];
 }
 
 static int wgrad_rows_grid(const MivpConvDesc* d) {
     const long rows = (long)d->B * d->dims[0] * d->dims[1];
-    long wg = (rows + 3) / 4;
-    if (wg > 512) wg = 512;
+    long wg = rows < 1024 ? rows : 1024;
     return (int)(wg < 1 ? 1 : wg);
 }
 
+static size_t wgrad_rows_lds(const MivpConvDesc* d) {
+    const int dp = (d->dims[2] + 31) / 32 * 32;
+    return (size_t)(dp / 4) * WR_AS * 128 + (size_t)((dp + 8) / 4) * WR_BS * 128;
+}
+
 extern "C" size_t mivp_conv3d_wgrad_rows_ws(const MivpConvDesc* d) {
-    int mt, ntc;
-    if (!d || wgrad_rows_cfg(d, &mt, &ntc)) return 0;
-    return (size_t)wgrad_rows_grid(d) * 4 * (16 * mt) * (16 * ntc);
+    if (!d || d->Cout > 8 || d->Cin + 1 > 64 || d->Cin % 8 || wgrad_rows_lds(d) > 160 * 1024) return 0;
+    return (size_t)wgrad_rows_grid(d) * 3 * 80 * 64;
 }
 
 extern "C" int mivp_conv3d_wgrad_rows(const MivpConvDesc* d, const void* x, const void* dy, int32_t dy_stride,
                                       float* part, float* gs, mivp_stream_t stream) {
     int rc = conv_checks(d);
     if (rc) return rc;
-    MIVP_REQUIRE(x && dy && part && gs && dy_stride >= d->Cout && d->Cout <= 8);
-    int mt, ntc;
-    if (wgrad_rows_cfg(d, &mt, &ntc)) { mivp_set_error("conv3d_wgrad_rows: needs 27*Cout <= 144 and Cin < 64"); return MIVP_EUNSUPPORTED; }
-    const int dp = (d->dims[2] + 31) / 32 * 32;
-    const size_t lds = (size_t)4 * 16 * (mt + ntc) * (dp + 8) * 2;
+    MIVP_REQUIRE(x && dy && part && gs);
+    if (d->Cout > 8 || dy_stride != 8 || d->Cin + 1 > 64 || d->Cin % 8) {
+        mivp_set_error("conv3d_wgrad_rows: needs Cout <= 8 with dy padded to 8 channels, Cin % 8 == 0, Cin < 64");
+        return MIVP_EUNSUPPORTED;
+    }
+    const size_t lds = wgrad_rows_lds(d);
     if (lds > 160 * 1024) { mivp_set_error("conv3d_wgrad_rows: D too long for the LDS row images"); return MIVP_EUNSUPPORTED; }
     const int grid = wgrad_rows_grid(d);
-    hipStream_t st = (hipStream_t)stream;
-#define WGR(M, N)                                                                                                   \
-    do {                                                                                                            \
-        auto kern = k_conv3d_wgrad_rows<M, N>;                                                                      \
-        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *d, (const bf16_t*)x, (const bf16_t*)dy, (int)dy_stride, part); \
-    } while (0)
-    if (mt == 4 && ntc == 1) WGR(4, 1);
-    else if (mt == 4 && ntc == 2) WGR(4, 2);
-    else if (mt == 4 && ntc == 4) WGR(4, 4);
-    else if (mt == 9 && ntc == 1) WGR(9, 1);
-    else if (mt == 9 && ntc == 2) WGR(9, 2);
-    else WGR(9, 4);
-#undef WGR
+    auto kern = k_conv3d_wgrad_rows;
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x, (const bf16_t*)dy, part);
     rc = mivp_check_launch("conv3d_wgrad_rows");
     if (rc) return rc;
-    return mivp_reduce_rows(part, (int64_t)grid * 4, (int64_t)(16 * mt) * (16 * ntc), gs, stream);
+    return mivp_reduce_rows(part, (int64_t)grid, (int64_t)3 * 80 * 64, gs, stream);
 }

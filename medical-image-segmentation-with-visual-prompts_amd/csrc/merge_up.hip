@@ -159,51 +159,46 @@ MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in) {
     return l;
 }
 
+// One workgroup per output row (b, oh, ow): the h/w interpolation (indices, weights, the four source row
+// pointers) is uniform for the block, a thread walks (od, channel group) items of the row -- no 64-bit divisions,
+// no weight-dependent branches (clamped neighbours are always in bounds, their weight is simply 0).
 __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t* __restrict__ x,
                                                    const bf16_t* __restrict__ skip, bf16_t* __restrict__ y) {
     const int Ct = d.Cx + d.Cs, G = Ct / 8, Gx = d.Cx / 8;
-    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
-    const long items = (long)d.B * ovol * G;
-    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
-    for (long it = gtid; it < items; it += stride) {
-        const long vox = it / G;
-        const int cg = (int)(it - vox * G);
+    const int OW = d.odims[1], OD = d.odims[2];
+    const int row = blockIdx.x;                               // (b*OH + oh)*OW + ow
+    const int ow = row % OW;
+    const int boh = row / OW;
+    const int oh = boh % d.odims[0];
+    const int b = boh / d.odims[0];
+    const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0]);
+    const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1]);
+    const long in_row = (long)d.idims[2] * d.Cx;
+    const bf16_t* r00 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i0) * in_row;
+    const bf16_t* r01 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i1) * in_row;
+    const bf16_t* r10 = x + (((long)b * d.idims[0] + lh.i1) * d.idims[1] + lw.i0) * in_row;
+    const bf16_t* r11 = x + (((long)b * d.idims[0] + lh.i1) * d.idims[1] + lw.i1) * in_row;
+    const float w00 = lh.w0 * lw.w0, w01 = lh.w0 * lw.w1, w10 = lh.w1 * lw.w0, w11 = lh.w1 * lw.w1;
+    bf16_t* yrow = y + (long)row * OD * Ct;
+    const bf16_t* srow = skip ? skip + (long)row * OD * d.Cs : nullptr;
+    for (int it = threadIdx.x; it < OD * G; it += 256) {
+        const int od = it / G, cg = it - od * G;
         if (cg >= Gx) {
-            st8(y + vox * Ct + cg * 8, ld8(skip + vox * d.Cs + (cg - Gx) * 8));
+            st8(yrow + od * Ct + cg * 8, ld8(srow + od * d.Cs + (cg - Gx) * 8));
             continue;
         }
-        const long b = vox / ovol;
-        long rem = vox - b * ovol;
-        const int oh = (int)(rem / ((long)d.odims[1] * d.odims[2]));
-        rem -= (long)oh * d.odims[1] * d.odims[2];
-        const int ow = (int)(rem / d.odims[2]);
-        const int od = (int)(rem - (long)ow * d.odims[2]);
-        const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0]);
-        const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1]);
         const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2]);
-        float acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        const int hs[2] = {lh.i0, lh.i1}, wsx[2] = {lw.i0, lw.i1}, ds[2] = {ld.i0, ld.i1};
-        const float hw[2] = {lh.w0, lh.w1}, ww[2] = {lw.w0, lw.w1}, dw[2] = {ld.w0, ld.w1};
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float wgt = hw[a] * ww[bb] * dw[c];
-                    if (wgt != 0.f) {
-                        const bf16x8 v = ld8(x + (((b * d.idims[0] + hs[a]) * (long)d.idims[1] + wsx[bb]) * d.idims[2] + ds[c]) * d.Cx + cg * 8);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] += wgt * (float)v[i];
-                    }
-                }
+        const int o0 = ld.i0 * d.Cx + cg * 8, o1 = ld.i1 * d.Cx + cg * 8;
+        const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
+        const bf16x8 c0 = ld8(r10 + o0), c1 = ld8(r10 + o1), e0 = ld8(r11 + o0), e1 = ld8(r11 + o1);
         bf16x8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)acc[i];
-        st8(y + vox * Ct + cg * 8, o);
+        for (int i = 0; i < 8; ++i) {
+            const float v0 = w00 * (float)a0[i] + w01 * (float)b0[i] + w10 * (float)c0[i] + w11 * (float)e0[i];
+            const float v1 = w00 * (float)a1[i] + w01 * (float)b1[i] + w10 * (float)c1[i] + w11 * (float)e1[i];
+            o[i] = (bf16_t)(ld.w0 * v0 + ld.w1 * v1);
+        }
+        st8(yrow + od * Ct + cg * 8, o);
     }
 }
 
@@ -214,9 +209,9 @@ extern "C" int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void*
         MIVP_REQUIRE(d->scale[a] == 1 || d->scale[a] == 2);
         MIVP_REQUIRE(d->odims[a] > 0 && d->odims[a] <= d->scale[a] * d->idims[a]);
     }
-    const long items = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2] * ((d->Cx + d->Cs) / 8);
-    const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
-    hipLaunchKernelGGL(k_upcat_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)x,
+    const long rows = (long)d->B * d->odims[0] * d->odims[1];
+    MIVP_REQUIRE(rows < (1L << 31));
+    hipLaunchKernelGGL(k_upcat_fwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)x,
                        (const bf16_t*)skip, (bf16_t*)y);
     return mivp_check_launch("upcat_fwd");
 }

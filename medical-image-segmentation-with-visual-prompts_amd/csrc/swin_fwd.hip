@@ -322,11 +322,11 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                     acc[2] = classify_logit(acc[2], kr.z, rq, live);
                     acc[3] = classify_logit(acc[3], kr.w, rq, live);
                 }
-                sv[hh] = acc * LOG2E;
+                sv[hh] = acc;                                // natural-log units; log2(e) rides on the fma below
             }
             float pmax = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
                                fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
-            pmax = col_max(pmax);
+            pmax = col_max(pmax) * LOG2E;
             const float mnew = fmaxf(mrun, pmax);            // the first pair always holds valid content keys: finite
             const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
             mrun = mnew;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(sv[hh][j] - mnew); sv[hh][j] = p; psum += p; }
+                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mnew)); sv[hh][j] = p; psum += p; }
             lsum = lsum * alpha + psum;
             if (DROP) {                                      // attention dropout acts on P after the softmax sum
 #pragma unroll

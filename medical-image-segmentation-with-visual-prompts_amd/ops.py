@@ -107,33 +107,30 @@ def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
 
 
 def conv3d_wgrad_rows_supported(cin: int, cout: int, depth: int) -> bool:
-    """Shape window of mivp_conv3d_wgrad_rows (csrc/conv3d.hip: wgrad_rows_cfg + its 160 KiB LDS row images)."""
-    rows, cols = 27 * cout, cin + 1
-    mt = 4 if rows <= 64 else (9 if rows <= 144 else 0)
-    ntc = 1 if cols <= 16 else (2 if cols <= 32 else (4 if cols <= 64 else 0))
-    if not (mt and ntc) or cout > 8:
+    """Shape window of mivp_conv3d_wgrad_rows (csrc/conv3d.hip): Cout <= 8, Cin + 1 <= 64, row images within LDS."""
+    if cout > 8 or cin + 1 > 64 or cin % 8:
         return False
     dp = (depth + 31) // 32 * 32
-    return 4 * 16 * (mt + ntc) * (dp + 8) * 2 <= 160 * 1024
+    return (dp // 4) * 6 * 128 + ((dp + 8) // 4) * 4 * 128 <= 160 * 1024
 
 
 def conv3d_wgrad_rows(x, dy, cout):
     """MFMA weight-gradient core for small-Cout convs: returns (G, S) with
-    G[co, tap, ci] = sum_u dy[u - tap][co] * x[u][ci]  (raw x) and S[co, tap] = sum_{u in bounds} dy[u - tap][co]."""
+    G[co, tap, ci] = sum_u dy[u - tap][co] * x[u][ci]  (raw x) and S[co, tap] = sum_{u in bounds} dy[u - tap][co].
+    dy must carry 8 channels (zero padded)."""
     B, H, W, D, cin = x.shape
+    if dy.shape[-1] != 8:
+        raise RuntimeError("conv3d_wgrad_rows: dy must be padded to 8 channels")
     d = conv_desc(B, (H, W, D), cin, cout, False, False, False, False)
     ws = L.lib().mivp_conv3d_wgrad_rows_ws(C.byref(d))
     if ws == 0:
-        raise RuntimeError("conv3d_wgrad_rows: shape not supported (needs 27*Cout <= 144, Cin < 64)")
+        raise RuntimeError("conv3d_wgrad_rows: shape not supported (needs Cout <= 8, Cin % 8 == 0, Cin < 64)")
     part = torch.empty(ws, dtype=torch.float32, device=x.device)
-    mt = 4 if 27 * cout <= 64 else 9
-    ntc = 1 if cin + 1 <= 16 else (2 if cin + 1 <= 32 else 4)
-    gs = torch.empty((16 * mt, 16 * ntc), dtype=torch.float32, device=x.device)
-    L.call("mivp_conv3d_wgrad_rows", C.byref(d), L.ptr(x), L.ptr(dy), C.c_int32(dy.shape[-1]), L.ptr(part), L.ptr(gs),
-           L.stream())
-    G = gs[:27 * cout, :cin].reshape(cout, 27, cin)
-    S = gs[:27 * cout, cin].reshape(cout, 27)
-    return G, S
+    gs = torch.empty((3, 80, 64), dtype=torch.float32, device=x.device)
+    L.call("mivp_conv3d_wgrad_rows", C.byref(d), L.ptr(x), L.ptr(dy), C.c_int32(8), L.ptr(part), L.ptr(gs), L.stream())
+    # gs[sd][nb*8 + co][c]  ->  [co][tap = nb*3 + sd][c]
+    full = gs[:, :72].reshape(3, 9, 8, 64).permute(2, 1, 0, 3).reshape(8, 27, 64)
+    return full[:cout, :, :cin], full[:cout, :, cin]
 
 
 def head_grads_from_gs(G, S, conv_w, scale, shift, mean_rstd):
