@@ -9,13 +9,16 @@
 
 namespace {
 constexpr int LOSS_MAXC = 8;
-MIVP_DEV float log_sigmoid(float u) { return fminf(u, 0.f) - log1pf(__expf(-fabsf(u))); }
+// log(1 + e) with e in (0, 1]: the hardware log is accurate to ~1 ulp of the RESULT's magnitude near 1, i.e. an absolute
+// error <= 6e-8 -- far below the 1e-4 gradient tolerance -- and ~20x cheaper than log1pf
+MIVP_DEV float log_sigmoid(float u) { return fminf(u, 0.f) - __logf(1.f + __expf(-fabsf(u))); }
 MIVP_DEV float sigmoid(float u) { return 1.f / (1.f + __expf(-u)); }
 }
 
 // pass 1: per-block partial sums  [3*C (I, P, T per class) + 1 (focal sum)]  for ONE batch element per block row
+template <int C>
 __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restrict__ z, const float* __restrict__ y, long vol,
-                                                          int C, int c0, float gamma, int blocks_per_b,
+                                                          int c0, float gamma, int blocks_per_b,
                                                           float* __restrict__ part) {
     __shared__ float red[4][3 * LOSS_MAXC + 1];
     const int b = blockIdx.x / blocks_per_b, blk = blockIdx.x % blocks_per_b;
@@ -90,8 +93,9 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
 }
 
 // pass 2: dz = dL/dz  (f32, same layout as z)
+template <int C>
 __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict__ z, const float* __restrict__ y, long vol,
-                                                         int B, int C, int c0, float gamma, const float* __restrict__ stats,
+                                                         int B, int c0, float gamma, const float* __restrict__ stats,
                                                          float* __restrict__ dz) {
     const int K = 3 * LOSS_MAXC + 1;
     const long total = (long)B * vol;
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
 }
 
 extern "C" size_t mivp_dice_focal_ws(int32_t B, int64_t vol) {
-    long bpb = (vol + 256 * 16 - 1) / (256 * 16);
-    if (bpb > 256) bpb = 256;
+    long bpb = (vol + 256 * 4 - 1) / (256 * 4);
+    if (bpb > 1024) bpb = 1024;
     if (bpb < 1) bpb = 1;
     return (size_t)B * (bpb + 1) * (3 * LOSS_MAXC + 1);
 }
@@ -152,15 +156,22 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
     MIVP_REQUIRE(logits && target && workspace && loss && dlogits);
     MIVP_REQUIRE(B > 0 && vol > 0 && C >= 2 && C <= LOSS_MAXC);
     const int K = 3 * LOSS_MAXC + 1;
-    long bpb = (vol + 256 * 16 - 1) / (256 * 16);
-    if (bpb > 256) bpb = 256;
+    long bpb = (vol + 256 * 4 - 1) / (256 * 4);
+    if (bpb > 1024) bpb = 1024;
     if (bpb < 1) bpb = 1;
     const int c0 = include_background ? 0 : 1;
     float* part = workspace;
     float* stats = workspace + (long)B * bpb * K;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_dice_focal_stats, dim3((unsigned)(B * bpb)), dim3(256), 0, st, logits, target, (long)vol, (int)C, c0,
-                       gamma, (int)bpb, part);
+#define LOSS_C_SWITCH(LAUNCH)                                                                        \
+    switch (C) {                                                                                     \
+        case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break; \
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;              \
+    }
+#define L_STATS(CC) hipLaunchKernelGGL((k_dice_focal_stats<CC>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, logits, target, \
+                                       (long)vol, c0, gamma, (int)bpb, part)
+    LOSS_C_SWITCH(L_STATS)
+#undef L_STATS
     int rc = mivp_check_launch("dice_focal_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(256), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
@@ -168,7 +179,10 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
     if (rc) return rc;
     const long total = (long)B * vol;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(k_dice_focal_grad, dim3(grid), dim3(256), 0, st, logits, target, (long)vol, (int)B, (int)C, c0, gamma,
-                       stats, dlogits);
+#define L_GRAD(CC) hipLaunchKernelGGL((k_dice_focal_grad<CC>), dim3(grid), dim3(256), 0, st, logits, target, (long)vol, (int)B, \
+                                      c0, gamma, stats, dlogits)
+    LOSS_C_SWITCH(L_GRAD)
+#undef L_GRAD
+#undef LOSS_C_SWITCH
     return mivp_check_launch("dice_focal_grad");
 }

@@ -93,9 +93,11 @@ __global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const 
         }
         xb[s] = yv;
     }
-    const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
+    // output tiles are split over gridDim.y (the deep stages have only a few dozen token groups)
     const int n_tiles = (d.Cout + 15) / 16;
-    for (int nt = 0; nt < n_tiles; ++nt) {
+    const int per_y = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const int nt_lo = blockIdx.y * per_y, nt_hi = (nt_lo + per_y) < n_tiles ? (nt_lo + per_y) : n_tiles;
+    for (int nt = nt_lo; nt < nt_hi; ++nt) {
         f32x4 acc = fzero4();
         const int nrow = 16 * nt + r;
 #pragma unroll
@@ -108,7 +110,6 @@ __global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const 
         const int n0 = 16 * nt + 4 * g;
         if (m.live && n0 < d.Cout) st4(y + t * d.Cout + n0, pack4(acc));
     }
-    (void)ovol;
 }
 
 extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const float* ln_w, const float* ln_b,
@@ -123,9 +124,14 @@ extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const
     const int kC = (d->merge_last ? 8 : 4) * d->C;
     const int KS = (kC + 31) / 32;
     const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
-    const unsigned grid = (unsigned)((T + 63) / 64);
+    const unsigned gx = (unsigned)((T + 63) / 64);
+    const int n_tiles = (d->Cout + 15) / 16;
+    int ny = (int)((1024 + gx - 1) / gx);                    // aim at >= 1024 workgroups
+    if (ny > n_tiles) ny = n_tiles;
+    if (ny < 1) ny = 1;
+    const dim3 grid(gx, (unsigned)ny);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_PM(K) hipLaunchKernelGGL((k_patch_merge_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)x, ln_w, ln_b, \
+#define LAUNCH_PM(K) hipLaunchKernelGGL((k_patch_merge_fwd<K>), grid, dim3(256), 0, st, *d, (const bf16_t*)x, ln_w, ln_b, \
                                          (const bf16_t*)w, (bf16_t*)y)
     switch (KS) {
         case 1: LAUNCH_PM(1); break;
