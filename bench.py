@@ -135,7 +135,8 @@ def main():
     # dominant kernel: the last decoder stage's conv_concat (implicit GEMM, K = 27*144, N = 48)
     hc = conf.hidden_channels
     dom_cin, dom_cout = hc[0] + hc[1], hc[0]
-    _lib.profile_select("mivp_conv3d_fwd", lambda a: a[0]._obj.Cin == dom_cin and a[0]._obj.Cout == dom_cout)
+    _lib.profile_select(("mivp_conv3d_halo_fwd", "mivp_conv3d_fwd"),
+                        lambda a: a[0]._obj.Cin == dom_cin and a[0]._obj.Cout == dom_cout)
 
     def sync():
         train.barrier_sync(dev)
@@ -170,7 +171,9 @@ def main():
         if kern_n:
             fl = conv_flops(kern_desc)
             achieved = fl / (kern_ms * 1e-3) / 1e12
-            roof = {"kernel": "k_conv3d_fwd<3,8,2> (decoder stage 2 conv_concat: 3x3x3 implicit GEMM, 144->48 channels, 48^3 voxels)",
+            kname = "k_conv3d_halo<3>" if _lib.profile_entry() == "mivp_conv3d_halo_fwd" else "k_conv3d_fwd<3,8,2>"
+            roof = {"kernel": f"{kname} (decoder stage 2 conv_concat: 3x3x3 conv as MFMA GEMM, {kern_desc.Cin}->{kern_desc.Cout} channels, "
+                              f"{kern_desc.dims[0]}x{kern_desc.dims[1]}x{kern_desc.dims[2]} voxels x batch {kern_desc.B})",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic_bytes(),
                     "launches_timed": kern_n, "avg_launch_ms": kern_ms, "flops_per_launch": fl}

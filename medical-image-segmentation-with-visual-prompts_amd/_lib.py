@@ -102,12 +102,13 @@ def call(name, *args):
 # ---------------------------------------------------------------------------------------------
 # optional per-kernel timing (bench.py): HIP events on the stream the kernel is launched on
 # ---------------------------------------------------------------------------------------------
-_prof = {"name": None, "pred": None, "on": False, "events": [], "desc": None}
+_prof = {"name": (), "pred": None, "on": False, "events": [], "desc": None, "entry": None}
 
 
 def profile_select(name, pred=None):
-    """Time every call of C-ABI entry ``name`` whose ctypes args satisfy ``pred`` while profiling is on."""
-    _prof.update(name=name, pred=pred, events=[], desc=None)
+    """Time every call of C-ABI entry ``name`` (a name or a tuple of names) whose ctypes args satisfy ``pred`` while
+    profiling is on."""
+    _prof.update(name=(name,) if isinstance(name, str) else tuple(name), pred=pred, events=[], desc=None, entry=None)
 
 
 def profile_reset(on: bool):
@@ -117,7 +118,7 @@ def profile_reset(on: bool):
 
 
 def profile_result():
-    """(mean launch duration in ms, launches, descriptor of the last timed launch)."""
+    """(mean launch duration in ms, launches, descriptor of the last timed launch); ``profile_entry()`` names it."""
     ev = _prof["events"]
     if not ev:
         return 0.0, 0, None
@@ -126,11 +127,15 @@ def profile_result():
     return sum(ms) / len(ms), len(ms), _prof["desc"]
 
 
+def profile_entry():
+    return _prof["entry"]
+
+
 _plain_call = call
 
 
 def call(name, *args):  # noqa: F811  (wraps the plain call with the optional event pair)
-    if _prof["on"] and name == _prof["name"] and (_prof["pred"] is None or _prof["pred"](args)):
+    if _prof["on"] and name in _prof["name"] and (_prof["pred"] is None or _prof["pred"](args)):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
@@ -139,5 +144,6 @@ def call(name, *args):  # noqa: F811  (wraps the plain call with the optional ev
         _prof["events"].append((a, b))
         d = args[0]._obj
         _prof["desc"] = type(d).from_buffer_copy(d)
+        _prof["entry"] = name
         return
     _plain_call(name, *args)

@@ -1,0 +1,215 @@
+// 3x3x3 stride-1 pad-1 convolution, "halo brick" form for LARGE volumes with few output channels
+// (the last decoder stage's conv_concat, swin_unetr/unet_blocks.py:46-56,74: 144 -> 48 channels at 48^3).
+//
+// The im2col kernel (conv3d.hip) fetches every input voxel 27 times through L1 -- once per tap -- and that
+// path, not the MFMA pipe, bounds it when Cout is small (few MACs per fetched byte).  Here a workgroup owns a
+// brick of 4 x 8 x 16 = 512 output voxels and stages the brick's 6 x 10 x 18 input halo ONCE per 16-channel
+// chunk in LDS; the 27 taps are then just LDS row offsets:
+//
+//   for chunk c of 16 input channels:                       (global -> registers one chunk ahead, double-buffered LDS)
+//       halo  [1080 rows][16 ch]        34.5 KB             rows = halo voxels, d fastest
+//       wts   [14 k-steps][Cout][32 k]  Cout * 0.9 KB       k-step j = taps (2j, 2j+1) x 16 channels (tap 27 = zeros)
+//       for j in 0..13:  every wave: 4 voxel-tile fragments + NTN weight fragments -> 4*NTN MFMAs
+//
+// One barrier per chunk (14 k-steps) instead of one per k-step; global traffic per MFMA is ~1/8 of the im2col
+// kernel's.  MFMA roles as everywhere (common.hpp): weight tile on operand A, voxel tile on operand B, so a lane
+// ends with one voxel and four consecutive output channels.
+//
+// LDS bank behaviour: ds_read_b128 is served in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... i.e.
+// lanes (r in 0-3|12-15, g) together with lanes (r in 4-11, g^1).  A voxel-tile fragment read takes halo rows
+// base + r (32 B apart) and the 16-byte half g&1, so inside a group the rows 8 apart -- the ones that share a
+// 32-byte bank window -- always take OPPOSITE halves: plain rows are conflict-free, no swizzle (an XOR on the row
+// index measured 32 % conflict cycles).  Both tap selections (g>>1) never meet in one group.  Weight rows are 64 B
+// with the chunk swizzle of conv3d.hip.
+#include "common.hpp"
+
+namespace {
+
+constexpr int HB_H = 4, HB_W = 8, HB_D = 16;                  // output brick
+constexpr int HH = HB_H + 2, HW = HB_W + 2, HD = HB_D + 2;    // halo
+constexpr int HROWS = HH * HW * HD;                           // 1080
+constexpr int HALO_BYTES = HROWS * 32;
+constexpr int KSTEPS = 14;                                    // 28 taps (27 + one zero tap) x 16 channels / 32
+constexpr int HTHREADS = 512;
+constexpr int HPIECES = (HROWS * 2 + HTHREADS - 1) / HTHREADS;     // 16-byte halo pieces per thread (5)
+
+MIVP_DEV int halo_off(int row, int half) { return row * 32 + (half << 4); }
+MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
+
+template <int NTN>
+__global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ wh, const float* __restrict__ bias,
+                                                          bf16_t* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 16 * NTN;
+    constexpr int WBYTES = KSTEPS * BN * 64;
+    constexpr int WPIECES = (WBYTES / 16 + HTHREADS - 1) / HTHREADS;
+    auto Hs = [&](int buf) -> char* { return smem + buf * (HALO_BYTES + WBYTES); };
+    auto Ws = [&](int buf) -> char* { return smem + buf * (HALO_BYTES + WBYTES) + HALO_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
+    const int nbh = (H + HB_H - 1) / HB_H, nbw = (W + HB_W - 1) / HB_W, nbd = (D + HB_D - 1) / HB_D;
+    // XCD-aware brick order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of bricks (shared halos in L2)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qb = nb >> 3, rb = nb & 7;
+    unsigned brick = (xcd < rb ? xcd * (qb + 1) : rb * (qb + 1) + (xcd - rb) * qb) + idx;
+    const int bd = brick % nbd; brick /= nbd;
+    const int bw = brick % nbw; brick /= nbw;
+    const int bh = brick % nbh;
+    const long b = brick / nbh;
+    const int h0 = bh * HB_H, w0 = bw * HB_W, d0 = bd * HB_D;
+
+    // ---- per-thread constants of the halo staging: element offset of each 16-byte piece (or -1: outside the volume)
+    long hsrc[HPIECES];
+    int hdst[HPIECES];
+#pragma unroll
+    for (int u = 0; u < HPIECES; ++u) {
+        const int p = tid + HTHREADS * u;
+        hsrc[u] = -1;
+        hdst[u] = -1;
+        if (p < HROWS * 2) {
+            const int row = p >> 1, half = p & 1;
+            const int hd = row % HD, hw = (row / HD) % HW, hh = row / (HD * HW);
+            const int gh = h0 + hh - 1, gw = w0 + hw - 1, gd = d0 + hd - 1;
+            hdst[u] = halo_off(row, half);
+            if ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && (unsigned)gd < (unsigned)D)
+                hsrc[u] = ((((long)b * H + gh) * W + gw) * D + gd) * Cin + 8 * half;
+        }
+    }
+    const int nchunks = Cin / 16;
+    bf16x8 hreg[HPIECES], wreg[WPIECES];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < HPIECES; ++u) hreg[u] = hsrc[u] >= 0 ? ld8(x + hsrc[u] + 16 * c) : zero8();
+        const bf16_t* wsrc = wh + (long)c * (WBYTES / 2);
+#pragma unroll
+        for (int u = 0; u < WPIECES; ++u) {
+            const int p = tid + HTHREADS * u;
+            wreg[u] = p < WBYTES / 16 ? ld8(wsrc + 8 * p) : zero8();
+        }
+    };
+    auto stage = [&](int buf) {
+        char* hs = Hs(buf);
+        char* ws = Ws(buf);
+#pragma unroll
+        for (int u = 0; u < HPIECES; ++u)
+            if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(hs + hdst[u]) = hreg[u];
+#pragma unroll
+        for (int u = 0; u < WPIECES; ++u) {
+            const int p = tid + HTHREADS * u;
+            if (p < WBYTES / 16) {
+                const int row = p >> 2, ch = p & 3;                    // row = kstep*BN + co
+                *reinterpret_cast<bf16x8*>(ws + row * 64 + 16 * wswz(row, ch)) = wreg[u];
+            }
+        }
+    };
+
+    // ---- this wave's four voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
+    const int th = wave >> 1, tw0 = (wave & 1) * 4;
+    const int half = g & 1, tsel = g >> 1;
+    int vbyte[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vbyte[i] = halo_off(((th * HW) + (tw0 + i)) * HD + r, half);
+    // weight fragment: row (16nt + r) of k-step j, chunk g under the row swizzle (constant per lane: j*BN and 16nt are multiples of 16)
+    const int wbyte = r * 64 + 16 * wswz(r, g);
+
+    f32x4 acc[4][NTN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) acc[i][nt] = fzero4();
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch(c + 1);
+        const char* hs = Hs(buf);
+        const char* ws = Ws(buf) + wbyte;
+        // fragments of k-step j+1 are read while the MFMAs of k-step j run (two register sets, loop fully unrolled)
+        bf16x8 vf[2][4], wf[2][NTN];
+        auto read_frags = [&](int j, int set) {
+            // taps 2j (lanes g < 2) and 2j+1 (g >= 2); tap 27 has zero weights, keep its rows in range
+            const int t0 = 2 * j, t1 = 2 * j + 1 < 27 ? 2 * j + 1 : 26;
+            const int o0 = (((t0 / 9) * HW + (t0 / 3) % 3) * HD + t0 % 3) * 32;
+            const int o1 = (((t1 / 9) * HW + (t1 / 3) % 3) * HD + t1 % 3) * 32;
+            const int toff = tsel ? o1 : o0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf[set][i] = *reinterpret_cast<const bf16x8*>(hs + vbyte[i] + toff);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) wf[set][nt] = *reinterpret_cast<const bf16x8*>(ws + (j * BN + 16 * nt) * 64);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < KSTEPS) read_frags(j + 1, cur ^ 1);
+            // the next chunk's tiles go to the other LDS buffer late in this chunk: the global loads issued at the top
+            // have landed by then and the writes overlap the remaining MFMAs (that buffer was last read in chunk c-1)
+            if (j == KSTEPS - 4 && c + 1 < nchunks) stage(buf ^ 1);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][nt] = mfma16(wf[cur][nt], vf[cur][i], acc[i][nt]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, bf16 store (lane: voxel r of tile i, channels 16nt + 4g .. +3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gh = h0 + th, gw = w0 + tw0 + i, gd = d0 + r;
+        if (gh < H && gw < W && gd < D) {
+            bf16_t* yrow = y + ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int co = 16 * nt + 4 * g;
+                if (co < d.Cout) {
+                    f32x4 v = acc[i][nt];
+                    if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
+                    st4(yrow + co, pack4(v));
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Shapes the halo kernel takes: Cin a multiple of 16, Cout a multiple of 4 and at most 48 (two halo buffers + two
+// weight buffers of 14 * Cout_p * 64 B must fit the 160 KB of LDS), plain bf16 output with optional bias.  Whether it
+// PAYS (enough bricks to fill 256 CUs) is the caller's call: mivp_amd/ops.py uses it from 512 bricks up.
+extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
+    if (!d || d->pro_affine || d->add_residual || d->out_f32) return 0;
+    if (d->Cin % 16 || d->Cout % 4 || d->Cout > 48 || d->Cout < 1) return 0;
+    return 1;
+}
+
+/* wh: bf16 [Cin/16][14][Cout_p][32] with Cout_p = Cout rounded up to 16; element (c, j, co, kk):
+ *   kk < 16 : weight[co][16c + kk][tap 2j]      kk >= 16 : weight[co][16c + kk - 16][tap 2j + 1]  (tap 27: zero) */
+extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias, void* y,
+                                    mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && wh && y);
+    if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
+    const int ntn = (d->Cout + 15) / 16;
+    const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + HB_W - 1) / HB_W) *
+                        ((d->dims[2] + HB_D - 1) / HB_D);
+    const size_t lds = 2 * ((size_t)HALO_BYTES + (size_t)KSTEPS * 16 * ntn * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define HALO_LAUNCH(N)                                                                                                   \
+    do {                                                                                                                 \
+        auto kern = k_conv3d_halo<N>;                                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)bricks), dim3(HTHREADS), lds, st, *d, (const bf16_t*)x, (const bf16_t*)wh, bias, \
+                           (bf16_t*)y);                                                                                  \
+    } while (0)
+    if (ntn == 1) HALO_LAUNCH(1);
+    else if (ntn == 2) HALO_LAUNCH(2);
+    else HALO_LAUNCH(3);
+#undef HALO_LAUNCH
+    return mivp_check_launch("conv3d_halo_fwd");
+}

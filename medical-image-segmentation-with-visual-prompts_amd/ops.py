@@ -62,13 +62,32 @@ def conv_desc(B, dims, cin, cout, affine, lrelu, residual, out_f32) -> L.ConvDes
     return d
 
 
+def halo_pack(wp: torch.Tensor, cin: int) -> torch.Tensor:
+    """Re-lay the im2col pack [Cout_p][tap*Cin + ci] for the halo-brick kernel: bf16 [Cin/16][14][Cout_p][32] where
+    k-step j holds taps (2j, 2j+1) x 16 channels (tap 27 = zeros).  Cached on the pack tensor (rebuilt with it)."""
+    wh = getattr(wp, "_mivp_halo", None)
+    if wh is None:
+        cout_p = wp.shape[0]
+        wt = torch.zeros((cout_p, 28, cin), dtype=BF16, device=wp.device)
+        wt[:, :27] = wp[:, :27 * cin].view(cout_p, 27, cin)
+        wh = wt.view(cout_p, 14, 2, cin // 16, 16).permute(3, 1, 0, 2, 4).reshape(cin // 16, 14, cout_p, 32).contiguous()
+        wp._mivp_halo = wh
+    return wh
+
+
 def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, lrelu: bool = False,
-           residual: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, out_f32: bool = False, force_halo: bool = False) -> torch.Tensor:
     B, H, W, D, cin = x.shape
     d = conv_desc(B, (H, W, D), cin, cout, scale is not None, lrelu, residual is not None, out_f32)
     if wp.shape != (round_up(cout, 16), d.Kp):
         raise RuntimeError(f"conv3d: packed weight shape {tuple(wp.shape)} does not match Cout={cout}, Cin={cin}")
+    bricks = B * ((H + 3) // 4) * ((W + 7) // 8) * ((D + 15) // 16)
+    if (force_halo or bricks >= 512) and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
+        # large volume, few output channels: the halo-brick kernel (each input voxel fetched once per workgroup)
+        y = torch.empty((B, H, W, D, cout), dtype=BF16, device=x.device)
+        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin)), L.ptr(bias), L.ptr(y), L.stream())
+        return y
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None

@@ -27,6 +27,30 @@ def cf(t):       # channels-last device -> [B,C,H,W,D] float cpu
     return t.float().cpu().permute(0, 4, 1, 2, 3)
 
 
+@pytest.mark.parametrize("cin,cout,dims,bias", [
+    (16, 16, (4, 8, 16), True),            # exactly one brick
+    (144, 48, (9, 13, 21), True),          # dec2 conv_concat channels; ragged bricks on every axis
+    (48, 8, (6, 5, 4), False),             # volume smaller than a brick
+    (32, 36, (8, 16, 32), True),           # Cout not a multiple of 16
+])
+def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
+    """The halo-brick form (csrc/conv3d_halo.hip) against F.conv3d and against the im2col kernel on the same input."""
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = r16(torch.randn(2, cin, *dims, generator=g))
+    w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1 if bias else None
+    want = F.conv3d(x, w, b, padding=1)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    bd = None if b is None else b.to(DEV)
+    y = ops.conv3d(cl(x), wp, bd, cout, force_halo=True)
+    y_ref = ops.conv3d(cl(x), wp, bd, cout)                 # few bricks -> the im2col kernel
+    torch.cuda.synchronize()
+    assert getattr(wp, "_mivp_halo", None) is not None     # the halo path really ran
+    assert rel_l2(cf(y), want) < 4e-3
+    assert rel_l2(cf(y), cf(y_ref)) < 2e-3
+
+
 @pytest.mark.parametrize("cin,cout,dims,affine,lrelu,res,f32", [
     (16, 16, (5, 6, 7), False, False, False, False),
     (24, 48, (6, 6, 8), True, True, False, False),      # Cin % 32 != 0: k-steps straddle taps
