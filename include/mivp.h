@@ -324,6 +324,30 @@ int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t
                     mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* downstream head on the LOW-resolution decoder output                      */
+/* (swin_unetr.py:351-355 nn.Upsample x2 trilinear, then :229-237 BatchNorm3d */
+/*  -> Conv3d 3^3): upsample, statistics, conv and the head's parameter       */
+/*  gradients are all linear in x [B,h,w,d,C] bf16, so the C-channel          */
+/*  full-resolution tensor is never formed.  C % 8 == 0, C < 64, Cout <= 4.   */
+/* ------------------------------------------------------------------------ */
+/* BatchNorm statistics of upsample(x): part [mivp_uphead_nblk(...)][2C] f32 partial (sum | sum of squares),   */
+/* reduce with mivp_bn_finalize exactly like mivp_bn_stats' output (count = 8*B*h*w*d)                         */
+int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w);
+int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
+                      mivp_stream_t stream);
+/* y [B,2h,2w,2d,Cout] f32 = bias + conv3x3x3(affine(upsample(x))).  wf: bf16 [16*ceil(27*Cout/16)][64], row
+ * tap*Cout + co = (weight[co][:, tap] * scale | sum_c weight[co][c, tap] * shift[c] | 0...): the BatchNorm affine
+ * folded into the weights, column C multiplying a constant-one channel.  workspace: mivp_uphead_fwd_ws bytes. */
+size_t mivp_uphead_fwd_ws(int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout);
+int mivp_uphead_fwd(const void* x, const void* wf, const float* bias, int32_t B, int32_t h, int32_t w, int32_t d,
+                    int32_t C, int32_t Cout, void* workspace, float* y, mivp_stream_t stream);
+/* D [B*h*w*d][ldD] bf16, column tap*Cout + co: the adjoint of the gather applied to dy [B,2h,2w,2d,dy_stride] f32.
+ * mivp_gemm_tn(D, x) then gives G[tap*Cout + co][c] = sum_u dy[u - tap][co] * upsample(x)[u][c] and the column
+ * sums of D give S = sum_{u in bounds} dy[u - tap][co]: the (G, S) of mivp_conv3d_wgrad_rows. */
+int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout,
+                        void* D, int32_t ldD, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* weight gradients: out[M][N] (+)= alpha * sum_t A[t][m] * B[t][n]          */
 /* (the dW of every nn.Linear / nn.Conv3d on the path when autograd reaches */
 /*  it: `loss.backward()` in segmentation.py:104, students_teacher.py:176)   */

@@ -70,6 +70,7 @@ def lib():
         _lib.mivp_dice_focal_ws.restype = C.c_size_t
         _lib.mivp_head_conv_ws.restype = C.c_size_t
         _lib.mivp_gemm_tn_ws.restype = C.c_size_t
+        _lib.mivp_uphead_fwd_ws.restype = C.c_size_t
         ver = _lib.mivp_abi_version()
         if ver != ABI_VERSION:
             raise RuntimeError(f"mivp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")

@@ -1,0 +1,427 @@
+// The downstream segmentation head WITHOUT its 48-channel full-resolution input.
+//
+// Reference: swin_unetr/swin_unetr.py:351-355 (output_layer = nn.Upsample(x2, trilinear, align_corners=False)) followed
+// by :229-237 (extra_heads['downstream'] = BatchNorm3d -> Conv3d 3^3, Cout = output_channels_downstream).  At 96^3 the
+// upsampled tensor is 340 MB per batch of 4 and every stage around it (upsample, BN statistics, head conv, head weight
+// gradient) is bound by streaming it.  All of them are linear in the LOW-resolution tensor x (U = the upsample matrix):
+//
+//   forward   y[u][co] = b[co] + sum_tap [u+tap inside] * (U Y_tap)[u+tap][co],    Y_tap[p][co] = sum_c W'[co][tap][c] x[p][c]
+//             (W' = conv weight with the BatchNorm affine folded in; a constant-one channel carries the shift, it
+//              upsamples to one and is masked with the tap at the zero-padded border exactly like the data)
+//   backward  G[co][tap][c] = sum_u dy[u - tap][co] * (U x)[u][c] = sum_p x[p][c] * D_tap[p][co],
+//             D_tap[p][co] = sum_u U[u + tap... ] (the adjoint of the gather above applied to dy)
+//
+// so the work at full resolution touches only Cout (= 2) channels:
+//   k_uphead_stats    BatchNorm statistics of U x from x (interpolates on the fly, no store)
+//   k_uphead_taps     Y = x W'^T on MFMA at low resolution -> fp16 planes [27][T_lr][Cout]
+//   k_uphead_gather   y from the 27 planes: one thread per low-res cell = 8 output voxels, static 2-point stencils
+//   k_uphead_adjoint  D (bf16 [T_lr][27*Cout]) from dy, separable accumulation; then mivp_gemm_tn(D, x) gives G
+// Trilinear weights: source index max(0, (o + 0.5)/2 - 0.5), neighbours clamped (ATen area_pixel_compute_source_index).
+#include "common.hpp"
+
+namespace {
+
+struct Lerp2 { int i0, i1; float w0, w1; };
+MIVP_DEV Lerp2 lerp2(int o, int n_in) {                       // scale 2
+    Lerp2 l;
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    if (src < 0.f) src = 0.f;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < n_in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel sum / sum of squares of the x2-upsampled tensor.  Block = ROWS output rows (b, oh, ow); a thread keeps
+// one 8-channel group (blockDim is a multiple of C/8) and walks od.  part[block][2C], fixed-order block reduction.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_ROWS = 8;
+__global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__ x, int B, int h, int w, int d, int C,
+                                                      float* __restrict__ part) {
+    __shared__ float lds[256 * 16];
+    const int G = C / 8, nth = blockDim.x, per = nth / G;      // per = threads per channel group
+    const int cg = threadIdx.x % G, slot = threadIdx.x / G;
+    const int OH = 2 * h, OW = 2 * w, OD = 2 * d;
+    const long rows = (long)B * OH * OW;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int rr = 0; rr < ST_ROWS; ++rr) {
+        const long row = (long)blockIdx.x * ST_ROWS + rr;
+        if (row >= rows) break;
+        const int ow = (int)(row % OW);
+        const long boh = row / OW;
+        const int oh = (int)(boh % OH);
+        const long b = boh / OH;
+        const Lerp2 lh = lerp2(oh, h), lw = lerp2(ow, w);
+        const long in_row = (long)d * C;
+        const bf16_t* r00 = x + ((b * h + lh.i0) * w + lw.i0) * in_row + cg * 8;
+        const bf16_t* r01 = x + ((b * h + lh.i0) * w + lw.i1) * in_row + cg * 8;
+        const bf16_t* r10 = x + ((b * h + lh.i1) * w + lw.i0) * in_row + cg * 8;
+        const bf16_t* r11 = x + ((b * h + lh.i1) * w + lw.i1) * in_row + cg * 8;
+        const float w00 = lh.w0 * lw.w0, w01 = lh.w0 * lw.w1, w10 = lh.w1 * lw.w0, w11 = lh.w1 * lw.w1;
+        for (int od = slot; od < OD; od += per) {
+            const Lerp2 ld = lerp2(od, d);
+            const int o0 = ld.i0 * C, o1 = ld.i1 * C;
+            const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
+            const bf16x8 c0 = ld8(r10 + o0), c1 = ld8(r10 + o1), e0 = ld8(r11 + o0), e1 = ld8(r11 + o1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v0 = w00 * (float)a0[i] + w01 * (float)b0[i] + w10 * (float)c0[i] + w11 * (float)e0[i];
+                const float v1 = w00 * (float)a1[i] + w01 * (float)b1[i] + w10 * (float)c1[i] + w11 * (float)e1[i];
+                const float v = ld.w0 * v0 + ld.w1 * v1;
+                s1[i] += v;
+                s2[i] += v * v;
+            }
+        }
+    }
+    // fixed-order reduction: thread (slot, cg) -> lds; one thread per output channel adds its group's slots in order
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { lds[threadIdx.x * 16 + i] = s1[i]; lds[threadIdx.x * 16 + 8 + i] = s2[i]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += nth) {
+        const int which = o / C, c = o - which * C, g = c >> 3, i = c & 7;
+        float acc = 0.f;
+        for (int sl = 0; sl < per; ++sl) acc += lds[(sl * G + g) * 16 + which * 8 + i];
+        part[(long)blockIdx.x * 2 * C + o] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Y[tap][t][co] (fp16) = sum_c Wf[tap*Cout + co][c] * x[t][c] + Wf[..][C] * 1     (K = C + 1 <= 64, M = 27*Cout <= 16*MT)
+// ---------------------------------------------------------------------------------------------
+template <int MT, int COUT>
+__global__ __launch_bounds__(256) void k_uphead_taps(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf, long T, int C,
+                                                     _Float16* __restrict__ Y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
+    const bool live = t < T;
+    bf16x8 xb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int c = 32 * s + 8 * g;
+        bf16x8 v = zero8();
+        if (live) {
+            if (c + 8 <= C) v = ld8(x + t * C + c);
+            else if (c == C) v[0] = (bf16_t)1.0f;              // the constant-one channel (C % 8 == 0)
+        }
+        xb[s] = v;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 acc = fzero4();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = mfma16(ld8(wf + (long)(16 * mt + r) * 64 + 32 * s + 8 * g), xb[s], acc);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = 16 * mt + 4 * g + j;
+                if (m < 27 * COUT) Y[((long)(m / COUT) * T + t) * COUT + (m % COUT)] = (_Float16)acc[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather: one thread per low-res cell p = 8 output voxels 2p + a.  Per axis, output i = 2p + a + k (k = tap - 1) reads
+//   (a,k) = (0,-1): .75 N[-1] + .25 N[0]   (0,0): .25 N[-1] + .75 N[0]   (0,+1): .75 N[0] + .25 N[+1]
+//           (1,-1): .25 N[-1] + .75 N[0]   (1,0): .75 N[0] + .25 N[+1]   (1,+1): .25 N[0] + .75 N[+1]
+// of the CLAMPED neighbours N[m] = Y[clamp(p + m)], which reproduces the upsample's edge clamping exactly; taps whose
+// i falls outside [0, 2n) are the conv's zero padding and are masked.
+// ---------------------------------------------------------------------------------------------
+MIVP_DEV constexpr int up_lo(int a, int k) { return (a + k) <= 0 ? 0 : 1; }                     // index of the first neighbour (0: N[-1], 1: N[0])
+MIVP_DEV constexpr float up_w0(int a, int k) { return ((a + k) == -1 || (a + k) == 1) ? 0.75f : 0.25f; }
+
+template <int COUT>
+__global__ __launch_bounds__(256) void k_uphead_gather(const _Float16* __restrict__ Y, const float* __restrict__ bias, int B,
+                                                       int h, int w, int d, float* __restrict__ y) {
+    const long T = (long)B * h * w * d;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= T) return;
+    const int p2 = (int)(p % d);
+    long rest = p / d;
+    const int p1 = (int)(rest % w);
+    rest /= w;
+    const int p0 = (int)(rest % h);
+    const long b = rest / h;
+    int n0[3], n1[3], n2[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        n0[m] = min(max(p0 + m - 1, 0), h - 1);
+        n1[m] = min(max(p1 + m - 1, 0), w - 1);
+        n2[m] = min(max(p2 + m - 1, 0), d - 1);
+    }
+    float acc[8][COUT];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[c][co] = bias ? bias[co] : 0.f;
+
+    // the tap loop is fully unrolled: every neighbour index and weight below is a compile-time constant
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int k0 = tap / 9 - 1, k1 = (tap / 3) % 3 - 1, k2 = tap % 3 - 1;
+        const _Float16* Yt = Y + (long)tap * T * COUT;
+        float N[3][3][3][COUT];
+#pragma unroll
+        for (int m0 = 0; m0 < 3; ++m0)
+#pragma unroll
+            for (int m1 = 0; m1 < 3; ++m1)
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2) {
+                    // slices no parity of this tap reads are skipped (k = -1 never touches N[+1], k = +1 never N[-1])
+                    if ((k0 == -1 && m0 == 2) || (k0 == 1 && m0 == 0) || (k1 == -1 && m1 == 2) || (k1 == 1 && m1 == 0) ||
+                        (k2 == -1 && m2 == 2) || (k2 == 1 && m2 == 0)) continue;
+                    const _Float16* src = Yt + ((((b * h + n0[m0]) * w + n1[m1]) * d) + n2[m2]) * COUT;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) N[m0][m1][m2][co] = (float)src[co];
+                }
+        const bool in0[2] = {(unsigned)(2 * p0 + k0) < (unsigned)(2 * h), (unsigned)(2 * p0 + 1 + k0) < (unsigned)(2 * h)};
+        const bool in1[2] = {(unsigned)(2 * p1 + k1) < (unsigned)(2 * w), (unsigned)(2 * p1 + 1 + k1) < (unsigned)(2 * w)};
+        const bool in2[2] = {(unsigned)(2 * p2 + k2) < (unsigned)(2 * d), (unsigned)(2 * p2 + 1 + k2) < (unsigned)(2 * d)};
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            // separable: interpolate along d, then w, then h
+            float R[3][3][2];
+#pragma unroll
+            for (int m0 = 0; m0 < 3; ++m0)
+#pragma unroll
+                for (int m1 = 0; m1 < 3; ++m1)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        if ((k0 == -1 && m0 == 2) || (k0 == 1 && m0 == 0) || (k1 == -1 && m1 == 2) || (k1 == 1 && m1 == 0)) continue;
+                        const int lo = up_lo(a2, k2);
+                        const float wa = up_w0(a2, k2);
+                        R[m0][m1][a2] = wa * N[m0][m1][lo][co] + (1.f - wa) * N[m0][m1][lo + 1][co];
+                    }
+            float Q[3][2][2];
+#pragma unroll
+            for (int m0 = 0; m0 < 3; ++m0)
+#pragma unroll
+                for (int a1 = 0; a1 < 2; ++a1)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        if ((k0 == -1 && m0 == 2) || (k0 == 1 && m0 == 0)) continue;
+                        const int lo = up_lo(a1, k1);
+                        const float wa = up_w0(a1, k1);
+                        Q[m0][a1][a2] = wa * R[m0][lo][a2] + (1.f - wa) * R[m0][lo + 1][a2];
+                    }
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 2; ++a1)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int lo = up_lo(a0, k0);
+                        const float wa = up_w0(a0, k0);
+                        const float v = wa * Q[lo][a1][a2] + (1.f - wa) * Q[lo + 1][a1][a2];
+                        acc[(a0 * 2 + a1) * 2 + a2][co] += (in0[a0] && in1[a1] && in2[a2]) ? v : 0.f;
+                    }
+        }
+    }
+    const int OH = 2 * h, OW = 2 * w, OD = 2 * d;
+#pragma unroll
+    for (int a0 = 0; a0 < 2; ++a0)
+#pragma unroll
+        for (int a1 = 0; a1 < 2; ++a1)
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                float* dst = y + ((((b * OH + 2 * p0 + a0) * OW + 2 * p1 + a1) * OD) + 2 * p2 + a2) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) dst[co] = acc[(a0 * 2 + a1) * 2 + a2][co];
+            }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// adjoint of the gather: D[q][tap*COUT + co] = sum_u [u + tap inside] * U3[u + tap, q] * dy[u][co]   (bf16, row stride ldD)
+// Per axis the hr positions whose interpolation touches low-res q are i_j = 2q - 1 + j, j = 0..3, with weight c[j]
+// (lerp2 handles the clamped edges; i outside [0, 2n) is the conv's zero padding: weight 0), and u = i - k.
+// One thread per low-res cell, separable accumulation: d first (E), then w (F), then h (D).
+// ---------------------------------------------------------------------------------------------
+MIVP_DEV void axis_coef(int q, int n, float (&c)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 2 * q - 1 + j;
+        float v = 0.f;
+        if (i >= 0 && i < 2 * n) {
+            const Lerp2 l = lerp2(i, n);
+            v = (l.i0 == q ? l.w0 : 0.f) + (l.i1 == q ? l.w1 : 0.f);
+        }
+        c[j] = v;
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict__ dy, int dy_stride, int B, int h, int w, int d,
+                                                        bf16_t* __restrict__ D, int ldD) {
+    const long T = (long)B * h * w * d;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= T) return;
+    const int q2 = (int)(p % d);
+    long rest = p / d;
+    const int q1 = (int)(rest % w);
+    rest /= w;
+    const int q0 = (int)(rest % h);
+    const long b = rest / h;
+    float c0[4], c1[4], c2[4];
+    axis_coef(q0, h, c0);
+    axis_coef(q1, w, c1);
+    axis_coef(q2, d, c2);
+    const int OH = 2 * h, OW = 2 * w, OD = 2 * d;
+    float acc[3][3][3][COUT];
+#pragma unroll
+    for (int k0 = 0; k0 < 3; ++k0)
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] = 0.f;
+#pragma unroll
+    for (int v0 = 0; v0 < 6; ++v0) {
+        const int u0 = 2 * q0 - 2 + v0;
+        float F[3][3][COUT];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) F[k1][k2][co] = 0.f;
+        const bool ok0 = (unsigned)u0 < (unsigned)OH;
+#pragma unroll
+        for (int v1 = 0; v1 < 6; ++v1) {
+            const int u1 = 2 * q1 - 2 + v1;
+            const bool ok1 = ok0 && (unsigned)u1 < (unsigned)OW;
+            const float* row = dy + (((b * OH + (ok0 ? u0 : 0)) * OW + (ok1 ? u1 : 0)) * (long)OD) * dy_stride;
+            float rv[6][COUT];
+#pragma unroll
+            for (int v2 = 0; v2 < 6; ++v2) {
+                const int u2 = 2 * q2 - 2 + v2;
+                const bool ok = ok1 && (unsigned)u2 < (unsigned)OD;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) rv[v2][co] = ok ? row[(long)u2 * dy_stride + co] : 0.f;
+            }
+            // along d: tap index k2 (offset k = k2 - 1) reads u2 = i_j - k, i.e. local v2 = j + 1 - k = j + 2 - k2
+            float E[3][COUT];
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e += c2[j] * rv[j + 2 - k2][co];
+                    E[k2][co] = e;
+                }
+            // along w: this v1 serves tap k1 through j1 = v1 - 2 + k1
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1) {
+                const int j1 = v1 - 2 + k1;
+                if (j1 < 0 || j1 > 3) continue;
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) F[k1][k2][co] += c1[j1] * E[k2][co];
+            }
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < 3; ++k0) {
+            const int j0 = v0 - 2 + k0;
+            if (j0 < 0 || j0 > 3) continue;
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] += c0[j0] * F[k1][k2][co];
+        }
+    }
+    bf16_t* dst = D + p * ldD;
+#pragma unroll
+    for (int k0 = 0; k0 < 3; ++k0)
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) dst[((k0 * 3 + k1) * 3 + k2) * COUT + co] = (bf16_t)acc[k0][k1][k2][co];
+    for (int c = 27 * COUT; c < ldD; ++c) dst[c] = (bf16_t)0.0f;
+}
+
+}  // namespace
+
+static int uphead_checks(int B, int h, int w, int d, int C, int Cout) {
+    MIVP_REQUIRE(B > 0 && h > 0 && w > 0 && d > 0);
+    MIVP_REQUIRE(C % 8 == 0 && C + 1 <= 64);
+    MIVP_REQUIRE(Cout >= 1 && Cout <= 4);
+    return MIVP_OK;
+}
+
+extern "C" int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w) {
+    const long rows = (long)B * 2 * h * 2 * w;
+    return (int)((rows + ST_ROWS - 1) / ST_ROWS);
+}
+
+extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
+                                 mivp_stream_t stream) {
+    int rc = uphead_checks(B, h, w, d, C, 1);
+    if (rc) return rc;
+    MIVP_REQUIRE(x && part);
+    const int G = C / 8;
+    const int nth = (256 / G) * G;
+    hipLaunchKernelGGL(k_uphead_stats, dim3(mivp_uphead_nblk(B, h, w)), dim3(nth), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (int)B, (int)h, (int)w, (int)d, (int)C, part);
+    return mivp_check_launch("uphead_stats");
+}
+
+extern "C" size_t mivp_uphead_fwd_ws(int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout) {
+    return (size_t)27 * B * h * w * d * Cout * sizeof(_Float16);
+}
+
+extern "C" int mivp_uphead_fwd(const void* x, const void* wf, const float* bias, int32_t B, int32_t h, int32_t w, int32_t d,
+                               int32_t C, int32_t Cout, void* workspace, float* y, mivp_stream_t stream) {
+    int rc = uphead_checks(B, h, w, d, C, Cout);
+    if (rc) return rc;
+    MIVP_REQUIRE(x && wf && workspace && y);
+    const long T = (long)B * h * w * d;
+    hipStream_t st = (hipStream_t)stream;
+    _Float16* Y = (_Float16*)workspace;
+    const unsigned g1 = (unsigned)((T + 63) / 64), g2 = (unsigned)((T + 255) / 256);
+#define UP_FWD(MT, CO)                                                                                             \
+    do {                                                                                                           \
+        hipLaunchKernelGGL((k_uphead_taps<MT, CO>), dim3(g1), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, T, (int)C, Y); \
+        hipLaunchKernelGGL((k_uphead_gather<CO>), dim3(g2), dim3(256), 0, st, (const _Float16*)Y, bias, (int)B, (int)h, (int)w,     \
+                           (int)d, y);                                                                             \
+    } while (0)
+    switch (Cout) {
+        case 1: UP_FWD(2, 1); break;
+        case 2: UP_FWD(4, 2); break;
+        case 3: UP_FWD(6, 3); break;
+        default: UP_FWD(7, 4); break;
+    }
+#undef UP_FWD
+    return mivp_check_launch("uphead_fwd");
+}
+
+extern "C" int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout,
+                                   void* D, int32_t ldD, mivp_stream_t stream) {
+    int rc = uphead_checks(B, h, w, d, 8, Cout);
+    if (rc) return rc;
+    MIVP_REQUIRE(dy && D && dy_stride >= Cout && ldD >= 27 * Cout && ldD % 8 == 0);
+    const long T = (long)B * h * w * d;
+    const unsigned grid = (unsigned)((T + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+#define UP_ADJ(CO) hipLaunchKernelGGL((k_uphead_adjoint<CO>), dim3(grid), dim3(256), 0, st, dy, (int)dy_stride, (int)B, (int)h, (int)w, \
+                                      (int)d, (bf16_t*)D, (int)ldD)
+    switch (Cout) {
+        case 1: UP_ADJ(1); break;
+        case 2: UP_ADJ(2); break;
+        case 3: UP_ADJ(3); break;
+        default: UP_ADJ(4); break;
+    }
+#undef UP_ADJ
+    return mivp_check_launch("uphead_adjoint");
+}

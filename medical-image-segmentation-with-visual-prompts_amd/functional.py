@@ -351,6 +351,45 @@ def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
     return _BnActConvFn.apply(x, bn.weight, bn.bias, conv.weight, conv.bias, bn, wp, wd, lrelu, out_f32)
 
 
+class _UpHeadFn(torch.autograd.Function):
+    """Segmentation head on the LOW-resolution decoder output: logits = conv(BatchNorm(upsample_x2(x))) without ever
+    forming the upsampled tensor (csrc/uphead.hip).  The input carries no gradient here (frozen backbone without
+    prompts, or inference); the head's own four parameters do."""
+
+    @staticmethod
+    def forward(ctx, x, bn_w, bn_b, conv_w, conv_b, bn):
+        if bn.training:
+            scale, shift, mean_rstd = ops.uphead_batch_stats(
+                x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
+                bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
+            bn.num_batches_tracked += 1
+        else:
+            scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
+        cout = conv_w.shape[0]
+        y = ops.uphead_forward(x, ops.uphead_fold(conv_w, scale, shift), conv_b, cout)
+        ctx.save_for_backward(x, scale, shift, mean_rstd, conv_w)
+        ctx.cout = cout
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean_rstd, conv_w = ctx.saved_tensors
+        g = ctx.needs_input_grad
+        G, S = ops.uphead_gs(x, dy, ctx.cout)
+        dw, db, dgamma, dbeta = ops.head_grads_from_gs(G, S, conv_w, scale, shift, mean_rstd)
+        return (None, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None, db if g[4] else None, None)
+
+
+def uphead_applicable(x, bn, conv) -> bool:
+    """The low-res head path: x2 trilinear upsample straight into (BatchNorm -> conv 3^3) with few classes, and no
+    gradient wanted for x."""
+    return (not (torch.is_grad_enabled() and x.requires_grad)) and ops.uphead_supported(x.shape[-1], conv.out_channels)
+
+
+def uphead(bn, conv, x):
+    return _UpHeadFn.apply(x, bn.weight, bn.bias, conv.weight, conv.bias, bn)
+
+
 # ----------------------------------------------------------------------------------------------
 # upsample + crop + concat
 # ----------------------------------------------------------------------------------------------

@@ -112,6 +112,61 @@ def head_conv(x, conv_w, conv_b, scale, shift):
     return y
 
 
+# ------------------------------------------------------------------------------------------
+# downstream head on the low-resolution decoder output (csrc/uphead.hip)
+# ------------------------------------------------------------------------------------------
+def uphead_supported(cin: int, cout: int) -> bool:
+    return cin % 8 == 0 and cin + 1 <= 64 and 1 <= cout <= 2
+
+
+def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.1):
+    """Training-mode BatchNorm statistics of upsample_x2(x) computed from x: (scale, shift, mean_rstd)."""
+    B, h, w, d, Cc = x.shape
+    nblk = L.lib().mivp_uphead_nblk(C.c_int32(B), C.c_int32(h), C.c_int32(w))
+    part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+    L.call("mivp_uphead_stats", L.ptr(x), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(part),
+           L.stream())
+    return bn_finalize(part, nblk, Cc, 8 * B * h * w * d, weight, bias, eps, running_mean, running_var, momentum)
+
+
+def uphead_fold(conv_w, scale, shift):
+    """BatchNorm affine folded into the head conv: bf16 [Mp][64], row tap*Cout + co = (w*scale | sum_c w*shift | 0)."""
+    cout, cin = conv_w.shape[0], conv_w.shape[1]
+    wt = conv_w.detach().float().reshape(cout, cin, 27).permute(2, 0, 1)                 # [tap, co, c]
+    mp = round_up(27 * cout, 16)
+    wf = torch.zeros((mp, 64), dtype=torch.float32, device=conv_w.device)
+    wf[:27 * cout, :cin] = (wt * scale.view(1, 1, cin)).reshape(27 * cout, cin)
+    wf[:27 * cout, cin] = (wt * shift.view(1, 1, cin)).sum(-1).reshape(27 * cout)
+    return wf.to(BF16).contiguous()
+
+
+def uphead_forward(x, wf, conv_b, cout):
+    """f32 logits [B,2h,2w,2d,cout] = bias + conv3x3x3(BN-affine(upsample_x2(x))) from the low-res x."""
+    B, h, w, d, Cc = x.shape
+    ws_bytes = L.lib().mivp_uphead_fwd_ws(C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(cout))
+    ws = torch.empty(ws_bytes // 2, dtype=torch.float16, device=x.device)
+    y = torch.empty((B, 2 * h, 2 * w, 2 * d, cout), dtype=torch.float32, device=x.device)
+    L.call("mivp_uphead_fwd", L.ptr(x), L.ptr(wf), L.ptr(conv_b.detach().float().contiguous()), C.c_int32(B), C.c_int32(h),
+           C.c_int32(w), C.c_int32(d), C.c_int32(Cc), C.c_int32(cout), L.ptr(ws), L.ptr(y), L.stream())
+    return y
+
+
+def uphead_gs(x, dy, cout):
+    """(G, S) of the head as conv3d_wgrad_rows defines them, from the low-res x and dy [B,2h,2w,2d,cout] f32:
+    G[co, tap, c] = sum_u dy[u - tap][co] * upsample(x)[u][c],  S[co, tap] = sum_{u in bounds} dy[u - tap][co]."""
+    from .swin_ops import _colsum_bf16
+    B, h, w, d, Cc = x.shape
+    T = B * h * w * d
+    ld = round_up(27 * cout, 8)
+    dy = dy.contiguous().float()
+    D = torch.empty((T, ld), dtype=BF16, device=x.device)
+    L.call("mivp_uphead_adjoint", L.ptr(dy), C.c_int32(dy.shape[-1]), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d),
+           C.c_int32(cout), L.ptr(D), C.c_int32(ld), L.stream())
+    G = gemm_tn(D, operand_rows(ld), x, operand_rows(Cc), T, 27 * cout, Cc)                 # [tap*cout + co][c]
+    S = _colsum_bf16(D)[:27 * cout]
+    return G.view(27, cout, Cc).permute(1, 0, 2).contiguous(), S.view(27, cout).t().contiguous()
+
+
 def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):
     """dw [Cout,Cin,3,3,3] f32 and db [Cout] f32 for a small-Cout conv (segmentation heads)."""
     B, H, W, D, cin = x.shape

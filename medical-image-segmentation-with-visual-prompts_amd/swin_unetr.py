@@ -376,7 +376,9 @@ class SwinUnetR(nn.Module):
             feats.insert(0, enc)
         return feats
 
-    def forward_decoder(self, feats):
+    def forward_decoder(self, feats, upsample_output=True):
+        """``upsample_output=False`` (only with ``unetr_res_block == 'none'``) returns the last decoder stage's
+        low-resolution output, i.e. skips ``output_layer`` (the x2 trilinear upsample)."""
         c = self.conf
         depth = c.depth_unet
         dec = Fn.conv3d_plain(self, "bottleneck", self.bottleneck, feats[0], residual=feats[0])
@@ -386,7 +388,7 @@ class SwinUnetR(nn.Module):
                 skip = Fn.conv3d_plain(self, f"res{j}", self.residual_blocks[j], skip)
             dec = self.decoder_blocks[j](dec, skip, self._prompts("dec", j))
         if c.unetr_res_block == "none":
-            return Fn.upcat(dec, None, (2, 2, 2))
+            return Fn.upcat(dec, None, (2, 2, 2)) if upsample_output else dec
         skip = Fn.conv3d_plain(self, f"res{depth}", self.residual_blocks[depth], Fn.to_channels_last(feats[-1]))
         return self.output_layer(dec, skip, self._prompts("out", 0))
 
@@ -398,7 +400,15 @@ class SwinUnetR(nn.Module):
         feats = self.forward_swin_transformer(x)
         if mode == "self_supervised_learning_encoder":
             return self._encoder_outputs(feats)
-        latent = self.forward_decoder(feats)
+        if mode == "downstream" and self.conf.unetr_res_block == "none":
+            head = self.extra_heads["downstream"]
+            dec = self.forward_decoder(feats, upsample_output=False)
+            if Fn.uphead_applicable(dec, head[0], head[1]):
+                # upsample -> BatchNorm -> conv evaluated from the low-resolution tensor (csrc/uphead.hip)
+                return {"downstream": Fn.to_channels_first(Fn.uphead(head[0], head[1], dec))}
+            latent = Fn.upcat(dec, None, (2, 2, 2))
+        else:
+            latent = self.forward_decoder(feats)
         if mode == "downstream":
             seg = Fn.bn_act_conv(self, self.extra_heads["downstream"][0], self.extra_heads["downstream"][1], latent,
                                  lrelu=False, out_f32=True, key="head_downstream")

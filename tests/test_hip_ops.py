@@ -276,3 +276,44 @@ def test_head_conv_fused(cin, cout, dims):
     y = ops.head_conv(cl(x), w.to(DEV), b.to(DEV), scale.to(DEV), shift.to(DEV))
     torch.cuda.synchronize()
     assert rel_l2(cf(y), want) < 3e-3       # bf16 weights (scale folded in) and fp16 tap partials
+
+
+@pytest.mark.parametrize("C,cout,dims,training", [(48, 2, (6, 5, 7), True), (48, 2, (4, 4, 4), False), (8, 1, (3, 9, 2), True),
+                                                   (16, 2, (1, 2, 3), True)])
+def test_uphead_low_resolution_head(C, cout, dims, training):
+    """upsample x2 (trilinear, align_corners=False) -> BatchNorm3d -> Conv3d 3^3 evaluated from the low-resolution
+    tensor (csrc/uphead.hip): logits and the four parameter gradients against torch on the same bf16 input.
+    Tolerances: logits 4e-3 (fp16 tap planes), gradients 6e-3 (bf16 adjoint operand, fp32 sums)."""
+    import torch.nn as nn
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(C + cout + dims[0])
+    x = r16(torch.randn(2, C, *dims, generator=g) + 0.3)
+    bn, conv = nn.BatchNorm3d(C), nn.Conv3d(C, cout, 3, 1, 1)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(C, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(C, generator=g))
+        bn.running_var.copy_(1 + 0.2 * torch.rand(C, generator=g))
+    bn.train(training)
+    import copy
+    bn2, conv2 = copy.deepcopy(bn).to(DEV), copy.deepcopy(conv).to(DEV)
+    up = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)
+    y = conv(bn(up))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = cl(x)
+    assert Fn.uphead_applicable(xd, bn2, conv2)
+    out = Fn.uphead(bn2, conv2, xd)
+    out.backward(dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    assert out.shape == (2, 2 * dims[0], 2 * dims[1], 2 * dims[2], cout) and out.dtype == torch.float32
+    assert rel_l2(out.detach().cpu().permute(0, 4, 1, 2, 3), y.detach()) < 4e-3
+    assert rel_l2(conv2.weight.grad.cpu(), conv.weight.grad) < 6e-3
+    assert rel_l2(conv2.bias.grad.cpu(), conv.bias.grad) < 6e-3
+    assert rel_l2(bn2.weight.grad.cpu(), bn.weight.grad) < 6e-3
+    assert rel_l2(bn2.bias.grad.cpu(), bn.bias.grad) < 6e-3
+    if training:
+        assert rel_l2(bn2.running_mean.cpu(), bn.running_mean) < 2e-3
+        assert rel_l2(bn2.running_var.cpu(), bn.running_var) < 2e-3
+        assert int(bn2.num_batches_tracked) == int(bn.num_batches_tracked)
