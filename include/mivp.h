@@ -332,7 +332,7 @@ int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t
 /* ------------------------------------------------------------------------ */
 /* BatchNorm statistics of upsample(x): part [mivp_uphead_nblk(...)][2C] f32 partial (sum | sum of squares),   */
 /* reduce with mivp_bn_finalize exactly like mivp_bn_stats' output (count = 8*B*h*w*d)                         */
-int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w);
+int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w, int32_t d, int32_t C);
 int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
                       mivp_stream_t stream);
 /* y [B,2h,2w,2d,Cout] f32 = bias + conv3x3x3(affine(upsample(x))).  wf: bf16 [16*ceil(27*Cout/16)][64], row

@@ -70,8 +70,13 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
     __syncthreads();
     // one wave per (b, k) sum: lanes stride over the per-block partials, then a butterfly (fixed order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    for (int i = wv; i < B * K; i += nwv) {
-        const int b = i / K, k = i - b * K;
+    const int used = 3 * C + 1;                                   // columns 0 .. 3C-1 and the focal sum; the rest stay zero
+    for (int i = wv; i < B * K; i += nwv) stats[i] = 0.f;
+    __syncthreads();
+    for (int ii = wv; ii < B * used; ii += nwv) {
+        const int b = ii / used, kk = ii - b * used;
+        const int k = kk < 3 * C ? kk : 3 * LOSS_MAXC;
+        const int i = b * K + k;
         double s = 0.0;
         for (int j = lane; j < blocks_per_b; j += 64) s += (double)part[((long)b * blocks_per_b + j) * K + k];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -174,7 +179,7 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
 #undef L_STATS
     int rc = mivp_check_launch("dice_focal_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(256), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
+    hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(1024), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
     rc = mivp_check_launch("dice_focal_finalize");
     if (rc) return rc;
     const long total = (long)B * vol;

@@ -34,59 +34,64 @@ MIVP_DEV Lerp2 lerp2(int o, int n_in) {                       // scale 2
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-channel sum / sum of squares of the x2-upsampled tensor.  Block = ROWS output rows (b, oh, ow); a thread keeps
-// one 8-channel group (blockDim is a multiple of C/8) and walks od.  part[block][2C], fixed-order block reduction.
+// per-channel sum / sum of squares of the x2-upsampled tensor U x, from x alone.  Per axis the columns of U sum to 2
+// and its Gram matrix U^T U is tridiagonal: diagonal 1.25 (1.625 at the two clamped ends, 2 if the axis has one
+// cell), off-diagonal 0.375.  Hence
+//     sum_u (Ux)[u]    = 8 * sum_p x[p]
+//     sum_u (Ux)[u]^2  = sum_p sum_{m in {-1,0,1}^3, p+m inside} g0(p0,m0) g1(p1,m1) g2(p2,m2) * x[p] * x[p+m]
+// i.e. a 27-point product stencil at LOW resolution (3x fewer multiply-adds than interpolating every output
+// voxel, and no full-resolution pass at all).  Work item = (cell, 8-channel group); a thread keeps its channel
+// group (total threads is a multiple of C/8), blocks reduce in a fixed order: part[block][2C].
 // ---------------------------------------------------------------------------------------------
-constexpr int ST_ROWS = 8;
+MIVP_DEV float gram_w(int p, int m, int n) {                 // (U^T U)[p][p+m] along one axis, 0 when p+m is outside
+    if (m == 0) return n == 1 ? 2.0f : ((p == 0 || p == n - 1) ? 1.625f : 1.25f);
+    return ((unsigned)(p + m) < (unsigned)n) ? 0.375f : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__ x, int B, int h, int w, int d, int C,
                                                       float* __restrict__ part) {
     __shared__ float lds[256 * 16];
-    const int G = C / 8, nth = blockDim.x, per = nth / G;      // per = threads per channel group
-    const int cg = threadIdx.x % G, slot = threadIdx.x / G;
-    const int OH = 2 * h, OW = 2 * w, OD = 2 * d;
-    const long rows = (long)B * OH * OW;
+    const int G = C / 8;
+    const long T = (long)B * h * w * d, items = T * G;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int cg = (int)(gtid % G);
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    for (int rr = 0; rr < ST_ROWS; ++rr) {
-        const long row = (long)blockIdx.x * ST_ROWS + rr;
-        if (row >= rows) break;
-        const int ow = (int)(row % OW);
-        const long boh = row / OW;
-        const int oh = (int)(boh % OH);
-        const long b = boh / OH;
-        const Lerp2 lh = lerp2(oh, h), lw = lerp2(ow, w);
-        const long in_row = (long)d * C;
-        const bf16_t* r00 = x + ((b * h + lh.i0) * w + lw.i0) * in_row + cg * 8;
-        const bf16_t* r01 = x + ((b * h + lh.i0) * w + lw.i1) * in_row + cg * 8;
-        const bf16_t* r10 = x + ((b * h + lh.i1) * w + lw.i0) * in_row + cg * 8;
-        const bf16_t* r11 = x + ((b * h + lh.i1) * w + lw.i1) * in_row + cg * 8;
-        const float w00 = lh.w0 * lw.w0, w01 = lh.w0 * lw.w1, w10 = lh.w1 * lw.w0, w11 = lh.w1 * lw.w1;
-        for (int od = slot; od < OD; od += per) {
-            const Lerp2 ld = lerp2(od, d);
-            const int o0 = ld.i0 * C, o1 = ld.i1 * C;
-            const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
-            const bf16x8 c0 = ld8(r10 + o0), c1 = ld8(r10 + o1), e0 = ld8(r11 + o0), e1 = ld8(r11 + o1);
+    for (long it = gtid; it < items; it += stride) {
+        const long p = it / G;
+        const int p2 = (int)(p % d);
+        long rest = p / d;
+        const int p1 = (int)(rest % w);
+        rest /= w;
+        const int p0 = (int)(rest % h);
+        const bf16_t* xp = x + p * C + cg * 8;
+        const bf16x8 cv = ld8(xp);
+        float xc[8], q[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v0 = w00 * (float)a0[i] + w01 * (float)b0[i] + w10 * (float)c0[i] + w11 * (float)e0[i];
-                const float v1 = w00 * (float)a1[i] + w01 * (float)b1[i] + w10 * (float)c1[i] + w11 * (float)e1[i];
-                const float v = ld.w0 * v0 + ld.w1 * v1;
-                s1[i] += v;
-                s2[i] += v * v;
+        for (int i = 0; i < 8; ++i) { xc[i] = (float)cv[i]; q[i] = 0.f; s1[i] += 8.f * xc[i]; }
+#pragma unroll
+        for (int m0 = -1; m0 <= 1; ++m0) {
+            const float g0 = gram_w(p0, m0, h);
+#pragma unroll
+            for (int m1 = -1; m1 <= 1; ++m1) {
+                const float g01 = g0 * gram_w(p1, m1, w);
+#pragma unroll
+                for (int m2 = -1; m2 <= 1; ++m2) {
+                    const float gg = g01 * gram_w(p2, m2, d);
+                    if (gg != 0.f) {                             // zero only for neighbours outside the volume
+                        const bf16x8 nv = ld8(xp + (((long)m0 * w + m1) * d + m2) * C);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) q[i] += gg * (float)nv[i];
+                    }
+                }
             }
         }
-    }
-    // fixed-order reduction: thread (slot, cg) -> lds; one thread per output channel adds its group's slots in order
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { lds[threadIdx.x * 16 + i] = s1[i]; lds[threadIdx.x * 16 + 8 + i] = s2[i]; }
-    __syncthreads();
-    for (int o = threadIdx.x; o < 2 * C; o += nth) {
-        const int which = o / C, c = o - which * C, g = c >> 3, i = c & 7;
-        float acc = 0.f;
-        for (int sl = 0; sl < per; ++sl) acc += lds[(sl * G + g) * 16 + which * 8 + i];
-        part[(long)blockIdx.x * 2 * C + o] = acc;
+        for (int i = 0; i < 8; ++i) s2[i] += xc[i] * q[i];
     }
+    block_reduce_groups(lds, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,7 +286,9 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict_
             for (int k2 = 0; k2 < 3; ++k2)
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] = 0.f;
-#pragma unroll
+    // the h loop stays a real loop (its three tap weights are recomputed per slice) so that only one 6x6 slice of dy
+    // is in flight: fully unrolled, the 108 loads of a cell were hoisted together and spilled
+#pragma unroll 1
     for (int v0 = 0; v0 < 6; ++v0) {
         const int u0 = 2 * q0 - 2 + v0;
         float F[3][3][COUT];
@@ -298,12 +305,23 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict_
             const bool ok1 = ok0 && (unsigned)u1 < (unsigned)OW;
             const float* row = dy + (((b * OH + (ok0 ? u0 : 0)) * OW + (ok1 ? u1 : 0)) * (long)OD) * dy_stride;
             float rv[6][COUT];
+            if (COUT == 2 && dy_stride == 2) {
+                // u2 = 2q2-2 .. 2q2+3 is three aligned voxel pairs, each entirely inside or outside: three 16-byte loads
 #pragma unroll
-            for (int v2 = 0; v2 < 6; ++v2) {
-                const int u2 = 2 * q2 - 2 + v2;
-                const bool ok = ok1 && (unsigned)u2 < (unsigned)OD;
+                for (int pr = 0; pr < 3; ++pr) {
+                    const int u2 = 2 * q2 - 2 + 2 * pr;
+                    const bool ok = ok1 && (unsigned)u2 < (unsigned)OD;
+                    const float4 v = ok ? *reinterpret_cast<const float4*>(row + (long)u2 * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rv[2 * pr][0] = v.x; rv[2 * pr][COUT - 1] = v.y; rv[2 * pr + 1][0] = v.z; rv[2 * pr + 1][COUT - 1] = v.w;
+                }
+            } else {
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) rv[v2][co] = ok ? row[(long)u2 * dy_stride + co] : 0.f;
+                for (int v2 = 0; v2 < 6; ++v2) {
+                    const int u2 = 2 * q2 - 2 + v2;
+                    const bool ok = ok1 && (unsigned)u2 < (unsigned)OD;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) rv[v2][co] = ok ? row[(long)u2 * dy_stride + co] : 0.f;
+                }
             }
             // along d: tap index k2 (offset k = k2 - 1) reads u2 = i_j - k, i.e. local v2 = j + 1 - k = j + 2 - k2
             float E[3][COUT];
@@ -329,14 +347,14 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict_
         }
 #pragma unroll
         for (int k0 = 0; k0 < 3; ++k0) {
-            const int j0 = v0 - 2 + k0;
-            if (j0 < 0 || j0 > 3) continue;
+            const int j0 = v0 - 2 + k0;                            // c0[j0], 0 outside 0..3 (selects: v0 is a run-time value)
+            const float cw = j0 == 0 ? c0[0] : (j0 == 1 ? c0[1] : (j0 == 2 ? c0[2] : (j0 == 3 ? c0[3] : 0.f)));
 #pragma unroll
             for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
                 for (int k2 = 0; k2 < 3; ++k2)
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] += c0[j0] * F[k1][k2][co];
+                    for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] += cw * F[k1][k2][co];
         }
     }
     bf16_t* dst = D + p * ldD;
@@ -360,9 +378,8 @@ static int uphead_checks(int B, int h, int w, int d, int C, int Cout) {
     return MIVP_OK;
 }
 
-extern "C" int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w) {
-    const long rows = (long)B * 2 * h * 2 * w;
-    return (int)((rows + ST_ROWS - 1) / ST_ROWS);
+extern "C" int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w, int32_t d, int32_t C) {
+    return (int)fixed_group_grid((long)B * h * w * d * (C / 8), C / 8, 2048);
 }
 
 extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
@@ -370,10 +387,8 @@ extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w,
     int rc = uphead_checks(B, h, w, d, C, 1);
     if (rc) return rc;
     MIVP_REQUIRE(x && part);
-    const int G = C / 8;
-    const int nth = (256 / G) * G;
-    hipLaunchKernelGGL(k_uphead_stats, dim3(mivp_uphead_nblk(B, h, w)), dim3(nth), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (int)B, (int)h, (int)w, (int)d, (int)C, part);
+    hipLaunchKernelGGL(k_uphead_stats, dim3(mivp_uphead_nblk(B, h, w, d, C)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (int)B, (int)h, (int)w, (int)d, (int)C, part);
     return mivp_check_launch("uphead_stats");
 }
 

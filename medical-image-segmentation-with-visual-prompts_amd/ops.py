@@ -122,7 +122,7 @@ def uphead_supported(cin: int, cout: int) -> bool:
 def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.1):
     """Training-mode BatchNorm statistics of upsample_x2(x) computed from x: (scale, shift, mean_rstd)."""
     B, h, w, d, Cc = x.shape
-    nblk = L.lib().mivp_uphead_nblk(C.c_int32(B), C.c_int32(h), C.c_int32(w))
+    nblk = L.lib().mivp_uphead_nblk(C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(Cc))
     part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
     L.call("mivp_uphead_stats", L.ptr(x), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(part),
            L.stream())
