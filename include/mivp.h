@@ -346,6 +346,11 @@ int mivp_uphead_fwd(const void* x, const void* wf, const float* bias, int32_t B,
  * sums of D give S = sum_{u in bounds} dy[u - tap][co]: the (G, S) of mivp_conv3d_wgrad_rows. */
 int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout,
                         void* D, int32_t ldD, mivp_stream_t stream);
+/* gradient w.r.t. x [B,h,w,d,C] (bf16) through upsample -> BatchNorm -> conv, all at low resolution:
+ *   D with ldD == 64; wc bf16 [16*ceil(C/16)][64] = conv weight as [c][tap*Cout + co] (zero padded);
+ *   coef f32 [4][C] = (BN scale | sum(dz)/N | rstd*sum(dz*xhat)/N | batch mean), rows 1-2 zero for eval-mode BN */
+int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, int32_t B, int32_t h, int32_t w,
+                   int32_t d, int32_t C, void* dx, mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* weight gradients: out[M][N] (+)= alpha * sum_t A[t][m] * B[t][n]          */

@@ -369,6 +369,69 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict_
     for (int c = 27 * COUT; c < ldD; ++c) dst[c] = (bf16_t)0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gradient w.r.t. the low-resolution input.  With z = scale*Ux + shift, dz = conv^T dy, the training-mode BatchNorm
+// backward is dUx = scale * (dz - S1/N - xhat * S2/N) (S1 = sum dz = dbeta, S2 = sum dz*xhat = dgamma, xhat = (Ux - mu) rstd)
+// and dx = U^T dUx.  Every piece lives at low resolution:
+//     U^T dz      = D Wc^T          (D = the adjoint tensor of k_uphead_adjoint, Wc[c][tap*Cout+co] = conv weight)
+//     U^T 1       = 8
+//     U^T (U x)   = the 27-point Gram stencil of k_uphead_stats applied to x
+//   dx[p][c] = scale_c * ( (D Wc^T)[p][c] - 8*k1_c - k2_c * (gram(x)[p][c] - 8*mu_c) ),  k1 = S1/N, k2 = rstd*S2/N
+// (eval-mode BatchNorm: k1 = k2 = 0).  One wave = 16 cells; MFMA for the D Wc^T part, lane = (cell r, 4 channels).
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void k_uphead_dx(const bf16_t* __restrict__ D, const bf16_t* __restrict__ wc,
+                                                   const bf16_t* __restrict__ x, const float* __restrict__ coef, int B, int h,
+                                                   int w, int d, int C, bf16_t* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long T = (long)B * h * w * d;
+    const long p = ((long)blockIdx.x * 4 + wave) * 16 + r;
+    const bool live = p < T;
+    const long pp = live ? p : 0;
+    bf16x8 db[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) db[s] = live ? ld8(D + pp * 64 + 32 * s + 8 * g) : zero8();
+    const int p2 = (int)(pp % d);
+    long rest = pp / d;
+    const int p1 = (int)(rest % w);
+    rest /= w;
+    const int p0 = (int)(rest % h);
+    const float* sc = coef, *k1 = coef + C, *k2 = coef + 2 * C, *mu = coef + 3 * C;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4 acc = fzero4();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = mfma16(ld8(wc + (long)(16 * ct + r) * 64 + 32 * s + 8 * g), db[s], acc);
+        const int c0 = 16 * ct + 4 * g;
+        if (!live || c0 >= C) continue;
+        f32x4 gram = fzero4();
+        const bf16_t* xp = x + pp * C + c0;
+#pragma unroll
+        for (int m0 = -1; m0 <= 1; ++m0) {
+            const float g0 = gram_w(p0, m0, h);
+#pragma unroll
+            for (int m1 = -1; m1 <= 1; ++m1) {
+                const float g01 = g0 * gram_w(p1, m1, w);
+#pragma unroll
+                for (int m2 = -1; m2 <= 1; ++m2) {
+                    const float gg = g01 * gram_w(p2, m2, d);
+                    if (gg != 0.f) {
+                        const bf16x4 nv = ld4(xp + (((long)m0 * w + m1) * d + m2) * C);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gram[j] += gg * (float)nv[j];
+                    }
+                }
+            }
+        }
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            out[j] = sc[c0 + j] * (acc[j] - 8.f * k1[c0 + j] - k2[c0 + j] * (gram[j] - 8.f * mu[c0 + j]));
+        st4(dx + pp * C + c0, pack4(out));
+    }
+}
+
 }  // namespace
 
 static int uphead_checks(int B, int h, int w, int d, int C, int Cout) {
@@ -439,4 +502,26 @@ extern "C" int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B
     }
 #undef UP_ADJ
     return mivp_check_launch("uphead_adjoint");
+}
+
+/* dx [B,h,w,d,C] bf16 from D (row stride 64, columns >= 27*Cout zero), wc bf16 [16*ceil(C/16)][64] = conv weight as
+ * [c][tap*Cout + co], coef f32 [4][C] = (scale | S1/N | rstd*S2/N | mean); see k_uphead_dx. */
+extern "C" int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, int32_t B, int32_t h, int32_t w,
+                              int32_t d, int32_t C, void* dx, mivp_stream_t stream) {
+    int rc = uphead_checks(B, h, w, d, C, 1);
+    if (rc) return rc;
+    MIVP_REQUIRE(D && wc && x && coef && dx);
+    const long T = (long)B * h * w * d;
+    const unsigned grid = (unsigned)((T + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define UP_DX(K) hipLaunchKernelGGL((k_uphead_dx<K>), dim3(grid), dim3(256), 0, st, (const bf16_t*)D, (const bf16_t*)wc,      \
+                                    (const bf16_t*)x, coef, (int)B, (int)h, (int)w, (int)d, (int)C, (bf16_t*)dx)
+    switch ((C + 15) / 16) {
+        case 1: UP_DX(1); break;
+        case 2: UP_DX(2); break;
+        case 3: UP_DX(3); break;
+        default: UP_DX(4); break;
+    }
+#undef UP_DX
+    return mivp_check_launch("uphead_dx");
 }

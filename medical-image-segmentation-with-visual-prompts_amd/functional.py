@@ -353,8 +353,8 @@ def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
 
 class _UpHeadFn(torch.autograd.Function):
     """Segmentation head on the LOW-resolution decoder output: logits = conv(BatchNorm(upsample_x2(x))) without ever
-    forming the upsampled tensor (csrc/uphead.hip).  The input carries no gradient here (frozen backbone without
-    prompts, or inference); the head's own four parameters do."""
+    forming the upsampled tensor (csrc/uphead.hip): forward, the head's four parameter gradients and the gradient
+    w.r.t. the low-resolution input."""
 
     @staticmethod
     def forward(ctx, x, bn_w, bn_b, conv_w, conv_b, bn):
@@ -369,21 +369,25 @@ class _UpHeadFn(torch.autograd.Function):
         y = ops.uphead_forward(x, ops.uphead_fold(conv_w, scale, shift), conv_b, cout)
         ctx.save_for_backward(x, scale, shift, mean_rstd, conv_w)
         ctx.cout = cout
+        ctx.training = bn.training
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean_rstd, conv_w = ctx.saved_tensors
         g = ctx.needs_input_grad
-        G, S = ops.uphead_gs(x, dy, ctx.cout)
+        if g[0]:
+            G, S, D = ops.uphead_gs(x, dy, ctx.cout, keep_d=True)
+        else:
+            G, S = ops.uphead_gs(x, dy, ctx.cout)
         dw, db, dgamma, dbeta = ops.head_grads_from_gs(G, S, conv_w, scale, shift, mean_rstd)
-        return (None, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None, db if g[4] else None, None)
+        dx = ops.uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, ctx.training) if g[0] else None
+        return (dx, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None, db if g[4] else None, None)
 
 
 def uphead_applicable(x, bn, conv) -> bool:
-    """The low-res head path: x2 trilinear upsample straight into (BatchNorm -> conv 3^3) with few classes, and no
-    gradient wanted for x."""
-    return (not (torch.is_grad_enabled() and x.requires_grad)) and ops.uphead_supported(x.shape[-1], conv.out_channels)
+    """The low-res head path: x2 trilinear upsample straight into (BatchNorm -> conv 3^3) with few classes."""
+    return ops.uphead_supported(x.shape[-1], conv.out_channels)
 
 
 def uphead(bn, conv, x):

@@ -151,20 +151,41 @@ def uphead_forward(x, wf, conv_b, cout):
     return y
 
 
-def uphead_gs(x, dy, cout):
+def uphead_gs(x, dy, cout, keep_d=False):
     """(G, S) of the head as conv3d_wgrad_rows defines them, from the low-res x and dy [B,2h,2w,2d,cout] f32:
-    G[co, tap, c] = sum_u dy[u - tap][co] * upsample(x)[u][c],  S[co, tap] = sum_{u in bounds} dy[u - tap][co]."""
+    G[co, tap, c] = sum_u dy[u - tap][co] * upsample(x)[u][c],  S[co, tap] = sum_{u in bounds} dy[u - tap][co].
+    ``keep_d`` also returns the adjoint tensor D [T, 64] (for uphead_dx)."""
     from .swin_ops import _colsum_bf16
     B, h, w, d, Cc = x.shape
     T = B * h * w * d
-    ld = round_up(27 * cout, 8)
+    ld = 64 if keep_d else round_up(27 * cout, 8)
     dy = dy.contiguous().float()
     D = torch.empty((T, ld), dtype=BF16, device=x.device)
     L.call("mivp_uphead_adjoint", L.ptr(dy), C.c_int32(dy.shape[-1]), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d),
            C.c_int32(cout), L.ptr(D), C.c_int32(ld), L.stream())
     G = gemm_tn(D, operand_rows(ld), x, operand_rows(Cc), T, 27 * cout, Cc)                 # [tap*cout + co][c]
     S = _colsum_bf16(D)[:27 * cout]
-    return G.view(27, cout, Cc).permute(1, 0, 2).contiguous(), S.view(27, cout).t().contiguous()
+    G, S = G.view(27, cout, Cc).permute(1, 0, 2).contiguous(), S.view(27, cout).t().contiguous()
+    return (G, S, D) if keep_d else (G, S)
+
+
+def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training):
+    """Gradient w.r.t. the low-res x through upsample -> BatchNorm -> conv (see k_uphead_dx)."""
+    B, h, w, d, Cc = x.shape
+    cout = conv_w.shape[0]
+    n_hr = float(8 * B * h * w * d)
+    wc = torch.zeros((round_up(Cc, 16), 64), dtype=torch.float32, device=x.device)
+    wc[:Cc, :27 * cout] = conv_w.detach().float().reshape(cout, Cc, 27).permute(1, 2, 0).reshape(Cc, 27 * cout)
+    coef = torch.zeros((4, Cc), dtype=torch.float32, device=x.device)
+    coef[0] = scale
+    if training:
+        coef[1] = dbeta / n_hr
+        coef[2] = mean_rstd[Cc:] * dgamma / n_hr
+    coef[3] = mean_rstd[:Cc]
+    dx = torch.empty_like(x)
+    L.call("mivp_uphead_dx", L.ptr(D), L.ptr(wc.to(BF16).contiguous()), L.ptr(x), L.ptr(coef), C.c_int32(B), C.c_int32(h),
+           C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(dx), L.stream())
+    return dx
 
 
 def conv3d_wgrad_small(x, scale, shift, lrelu, dy, cout):

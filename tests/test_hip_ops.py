@@ -288,7 +288,7 @@ def test_uphead_low_resolution_head(C, cout, dims, training):
     import mivp_amd
     from mivp_amd import functional as Fn
     g = torch.Generator().manual_seed(C + cout + dims[0])
-    x = r16(torch.randn(2, C, *dims, generator=g) + 0.3)
+    x = r16(torch.randn(2, C, *dims, generator=g) + 0.3).requires_grad_(True)
     bn, conv = nn.BatchNorm3d(C), nn.Conv3d(C, cout, 3, 1, 1)
     with torch.no_grad():
         bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
@@ -302,11 +302,12 @@ def test_uphead_low_resolution_head(C, cout, dims, training):
     y = conv(bn(up))
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
-    xd = cl(x)
+    xd = cl(x.detach()).requires_grad_(True)
     assert Fn.uphead_applicable(xd, bn2, conv2)
     out = Fn.uphead(bn2, conv2, xd)
     out.backward(dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
     torch.cuda.synchronize()
+    assert rel_l2(cf(xd.grad), x.grad) < 1e-2
     assert out.shape == (2, 2 * dims[0], 2 * dims[1], 2 * dims[2], cout) and out.dtype == torch.float32
     assert rel_l2(out.detach().cpu().permute(0, 4, 1, 2, 3), y.detach()) < 4e-3
     assert rel_l2(conv2.weight.grad.cpu(), conv.weight.grad) < 6e-3
