@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg2", "cfg3", "sup_all", "tiny"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg2", "cfg3", "cfg4", "sup_all", "tiny"])
     ap.add_argument("--window", default="7,7,7")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's)")
     ap.add_argument("--dropout", type=float, default=0.0, help="attn_drop = proj_drop (the yml default is 0.1)")

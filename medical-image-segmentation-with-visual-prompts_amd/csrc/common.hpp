@@ -62,19 +62,23 @@ MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live) {
 }
 
 // Counter-based dropout (no RNG state): one 32-bit hash serves the two elements of an index pair, 16 bits each.
-// murmur3's finaliser over (pair index * golden ratio + seed).
+// Two multiply / xor-shift rounds over (pair index * golden ratio + seed): the counters are consecutive integers, the
+// odd multipliers spread them over all 32 bits and each xor-shift folds the high half into the low one; the measured
+// drop rates sit within 2e-3 of p and the masks decorrelate across seeds (tests/test_hip_swin_bwd.py).  The attention
+// kernels are VALU-bound, so every operation here is paid for: 6 per hash.
 MIVP_DEV uint32_t drop_hash(uint32_t pair_idx, uint32_t seed) {
     uint32_t h = pair_idx * 0x9E3779B1u + seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu;
-    h ^= h >> 13; h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
+    h ^= h >> 15; h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h * 0xC2B2AE35u;
 }
 MIVP_DEV bool drop_keep(uint32_t h, int odd, uint32_t thr) { return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= thr); }
-// pair index of attention element (window-head bph, query q, key k): keys k and k^1 share a hash
-MIVP_DEV uint32_t attn_pair(long bph, int q, int k, int Nqp, int Nkp) {
-    return (uint32_t)((bph * Nqp + q) * (long)(Nkp >> 1) + (k >> 1));
+// pair index of attention element (window-head bph, query q, key k): keys k and k^1 share a hash.  All in 32-bit
+// arithmetic (wrap-around only re-uses counters between far-apart windows): attn_row() once per query row, then one add.
+MIVP_DEV uint32_t attn_row(long bph, int q, int Nqp, int Nkp) {
+    return ((uint32_t)bph * (uint32_t)Nqp + (uint32_t)q) * (uint32_t)(Nkp >> 1);
 }
+MIVP_DEV uint32_t attn_pair(uint32_t row, int k) { return row + (uint32_t)(k >> 1); }
 
 // LDS image of 16-byte-chunked operand rows read as MFMA fragments (lane = (row r, chunk g), ds_read_b128).
 // DK == 32: rows are exactly 64 bytes and the chunk index is XOR-swizzled with {0,3,2,1}[(row >> 2) & 3], which

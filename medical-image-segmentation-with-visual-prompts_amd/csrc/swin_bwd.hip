@@ -326,6 +326,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
             }
             const int rqi = rq[i];
             const float lsei = lse_b[i], dli = dl[i];
+            const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
             for (int u = 0; u < ntc / 2; ++u) {
                 f32x4 ds[2];
 #pragma unroll
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                             dp = mfma16(*reinterpret_cast<const bf16x8*>(Vimg + (size_t)(16 * lt + r) * VROWB + (32 * ks + 8 * g) * 2), dof[ks], dp);
                     }
                     if (DROP) {                              // dP = dropout'(dO V^T): same mask and scale as the forward
-                        const uint32_t pi = attn_pair(bph, qrow, 16 * (t0 + lt) + 4 * g, Nqp, Nkp);
+                        const uint32_t pi = attn_pair(drow, 16 * (t0 + lt) + 4 * g);
                         const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
                         dp[0] = drop_keep(h0, 0, d.attn_drop_thr) ? dp[0] * d.attn_drop_scale : 0.f;
                         dp[1] = drop_keep(h0, 1, d.attn_drop_thr) ? dp[1] * d.attn_drop_scale : 0.f;
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
             int kcls = -1;
             if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
             else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
+            const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
             bf16x8 kf[DKS];
 #pragma unroll
             for (int s = 0; s < DKS; ++s) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                         const float p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
                         float keep = 1.f;
                         if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
-                            const uint32_t hsh = drop_hash(attn_pair(bph, q0 + 16 * lt + 4 * g + j, krow, Nqp, Nkp), d.attn_seed);
+                            const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
                             keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                         }
                         const float dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_dropout_masks(MivpSwinDesc d, uint8_t* 
             const long rest = e / d.Nkp;
             const int q = (int)(rest % d.Nqp);
             const long bph = rest / d.Nqp;
-            const uint32_t h = drop_hash(attn_pair(bph, q, k, d.Nqp, d.Nkp), d.attn_seed);
+            const uint32_t h = drop_hash(attn_pair(attn_row(bph, q, d.Nqp, d.Nkp), k), d.attn_seed);
             attn_keep[e] = (d.attn_drop_thr == 0 || drop_keep(h, k & 1, d.attn_drop_thr)) ? 1 : 0;
         }
     }

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
         float mrun = -INFINITY, lsum = 0.f;                  // mrun already multiplied by log2(e)
+        const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
 
         for (int u = 0; u < npairs; ++u) {
             f32x4 sv[2];
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int key0 = 16 * (2 * u + hh) + 4 * g;
-                    const uint32_t pi = attn_pair(bph, qrow, key0, Nqp, Nkp);
+                    const uint32_t pi = attn_pair(drow, key0);
                     const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
                     sv[hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[hh][0] : 0.f;
                     sv[hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[hh][1] : 0.f;

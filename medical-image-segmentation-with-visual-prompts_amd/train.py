@@ -25,6 +25,10 @@ WORKLOADS = {
     # configs[3] (per-GPU shape): both prompt sides, 4-channel 128^3
     "cfg3": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=True,
                  input_channels=4, size=128, batch=1),
+    # configs[4] (per-GPU shape): prompt-token-only fine-tune of the frozen backbone at batch 8.  The config asks for fp8
+    # window attention; the attention kernels are exp/VALU-bound, so they stay bf16 here
+    "cfg4": dict(training_mode="downstream", use_encoder_prompting=True, use_decoder_prompting=False,
+                 input_channels=1, size=96, batch=8),
     # configs[0]: the reference's CPU-runnable plumbing case (all parameters train)
     "cfg0": dict(training_mode="self_supervised_learning_all", use_encoder_prompting=False, use_decoder_prompting=False,
                  input_channels=1, size=32, batch=2),

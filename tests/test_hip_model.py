@@ -278,6 +278,42 @@ def test_training_step_is_bitwise_reproducible(workload):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+@pytest.mark.parametrize("workload", ["cfg1", "cfg2"])
+def test_full_size_batch_elements_are_independent(workload):
+    """BASELINE.json's real shapes (96^3, 7^3 windows, the yml's channel widths) through size-independent properties:
+    in eval mode every volume is processed independently of its batch neighbours, so (a) a batch of two equals the two
+    single-volume runs (to rounding: split-K factors and the conv kernel choice depend on the batch size, so the
+    fp32 summation order does -- a cross-batch indexing bug would be an O(1) error) and (b) swapping the volumes swaps
+    the outputs bit for bit (same launch shapes, no reduction crosses the batch).  Exercises every forward kernel at the sizes the benchmark runs (343-token windows with the one-voxel pad,
+    halo-brick conv, low-resolution head); a training step on the same batch must give a finite loss and gradients."""
+    import mivp_amd
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, size, _ = train.make_conf(workload)
+    torch.manual_seed(1)
+    model = SwinUnetR(conf).to(DEV)
+    x, y = train.synthetic_batch(conf, 2, size, DEV)
+    model.eval()
+    with torch.no_grad():
+        both = model(x)["downstream"]
+        one0 = model(x[:1])["downstream"]
+        one1 = model(x[1:])["downstream"]
+        swapped = model(x.flip(0))["downstream"]
+    torch.cuda.synchronize()
+    assert both.shape == (2, conf.output_channels_downstream, size, size, size)
+    assert torch.isfinite(both).all()
+    assert rel_l2(both[:1].cpu(), one0.cpu()) < 1e-2 and rel_l2(both[1:].cpu(), one1.cpu()) < 1e-2
+    assert torch.equal(swapped, both.flip(0))
+    assert float((both[0] - both[1]).abs().max()) > 0          # the two volumes really differ
+    model.train()
+    opt = train.build_optimizer(model, conf)
+    loss = train.train_step(model, opt, conf, x, y)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    grads = [p.grad for _, p in model.named_parameters_downstream()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+
+
 def test_dropout_training_mode_end_to_end():
     """yml default attn_drop = proj_drop = 0.1: a training forward/backward runs, is reproducible under
     torch.manual_seed, changes with the seed, and eval mode ignores dropout."""
