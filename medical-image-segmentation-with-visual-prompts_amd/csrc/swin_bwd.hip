@@ -156,21 +156,22 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_win_attn_delta(MivpSwinDesc d, const bf16_t* __restrict__ o,
                                                         const bf16_t* __restrict__ d_o, float* __restrict__ delta) {
+    // one thread per (token, head), head fastest: a wave reads whole contiguous token rows of o and dO
     const int hd = d.C / d.heads;
-    const long total = (long)d.B * d.P * d.heads * d.Nqp;
+    const long tokens = (long)d.B * d.P * d.Nqp, total = tokens * d.heads;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int qrow = (int)(i % d.Nqp);
-        const long bph = i / d.Nqp;
-        const int head = (int)(bph % d.heads);
-        const long bp = bph / d.heads;
-        const long off = (bp * d.Nqp + qrow) * (long)d.C + head * hd;
+        const int head = (int)(i % d.heads);
+        const long tok = i / d.heads;
+        const long bp = tok / d.Nqp;
+        const int qrow = (int)(tok - bp * d.Nqp);
+        const long off = tok * (long)d.C + head * hd;
         float acc = 0.f;
         for (int j = 0; j < hd; j += 4) {
             const bf16x4 a = ld4(o + off + j), b = ld4(d_o + off + j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc += (float)a[e] * (float)b[e];
         }
-        delta[i] = acc;
+        delta[(bp * d.heads + head) * d.Nqp + qrow] = acc;
     }
 }
 
@@ -862,7 +863,7 @@ extern "C" int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const v
     if (rc) return rc;
     MIVP_REQUIRE(o && d_o && delta);
     const long total = (long)d->B * d->P * d->heads * d->Nqp;
-    const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(k_win_attn_delta, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)o,
                        (const bf16_t*)d_o, delta);
     return mivp_check_launch("win_attn_delta");

@@ -164,11 +164,13 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
                                                      const float* __restrict__ t_w, const float* __restrict__ t_d,
                                                      const float* __restrict__ ts, bf16_t* __restrict__ qa,
                                                      bf16_t* __restrict__ ka) {
+    // grid = (heads + 1, row chunks): block row `heads` writes the head-independent query one-hots
     const int head = blockIdx.x;
     const int w0 = d.win[0], w1 = d.win[1], w2 = d.win[2];
     const int A = d.augp;
-    if (head == 0) {
-        for (int e = threadIdx.x; e < d.Nqp * A; e += 256) {
+    const int chunk = blockIdx.y, nchunk = gridDim.y;
+    if (head == d.heads) {
+        for (int e = chunk * 256 + threadIdx.x; e < d.Nqp * A; e += nchunk * 256) {
             const int n = e / A, a = e - n * A;
             float val = 0.f;
             if (n < d.Nq) {
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
             }
             qa[e] = (bf16_t)val;
         }
+        return;
     }
     const float* th = t_h + (long)head * (2 * w0 - 1);
     const float* tw = t_w + (long)head * (2 * w1 - 1);
     const float* td = t_d + (long)head * (2 * w2 - 1);
-    for (int e = threadIdx.x; e < d.Nkp * A; e += 256) {
+    for (int e = chunk * 256 + threadIdx.x; e < d.Nkp * A; e += nchunk * 256) {
         const int m = e / A, a = e - m * A;
         float val = 0.f;
         if (m < d.Nq) {
@@ -553,7 +556,7 @@ extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const f
     if (rc) return rc;
     MIVP_REQUIRE(t_h && t_w && t_d && qa && ka);
     MIVP_REQUIRE(d->Np == 0 || ts != nullptr);
-    hipLaunchKernelGGL(k_relbias_aug, dim3(d->heads), dim3(256), 0, (hipStream_t)stream, *d, t_h, t_w, t_d, ts,
+    hipLaunchKernelGGL(k_relbias_aug, dim3(d->heads + 1, 8), dim3(256), 0, (hipStream_t)stream, *d, t_h, t_w, t_d, ts,
                        (bf16_t*)qa, (bf16_t*)ka);
     return mivp_check_launch("relbias_aug");
 }
