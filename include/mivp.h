@@ -185,12 +185,14 @@ typedef struct MivpMergeDesc {
 /* x [B,H,W,D,C] bf16 -> y [B,oh,ow,od,Cout] bf16 ; w [Cout][kC] bf16 ; ln over kC */
 int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const float* ln_w, const float* ln_b,
                          const void* w, void* y, mivp_stream_t stream);
-/* dy -> dx ; w_t [kC][Cout] bf16
+/* dy -> dx ; w_t [kC][Cout] bf16; yfwd = the forward output [T][Cout] bf16; wgam[n] = sum_c W[n][c]*gamma[c] and
+ * wbet[n] = sum_c W[n][c]*beta[c] (f32 [Cout], W = the bf16 weight): the LayerNorm-backward row sums follow from
+ * dy, yfwd and these two vectors without a second GEMM.
  *   weight-gradient mode (both or NULL): wg_dn, wg_x [T][kC] bf16 = gradient w.r.t. the LayerNorm output and the
  *   gathered LayerNorm input rows */
-int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
-                         const float* ln_b, const void* w_t, void* dx, void* wg_dn, void* wg_x,
-                         mivp_stream_t stream);
+int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const void* yfwd, const float* ln_w,
+                         const float* ln_b, const float* wgam, const float* wbet, const void* w_t, void* dx,
+                         void* wg_dn, void* wg_x, mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* 3x3x3 stride-1 pad-1 convolution as implicit GEMM                         */

@@ -312,17 +312,22 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 backward: dy [T][Cout] -> dx.  dYn = dy W (A = W^T rows = concat channel) -> LayerNorm
-// backward over the kC-long gathered row -> scatter to the 8 (4) source voxels.  The kC-long row
-// does not fit in registers next to the MFMA operands, so the row is walked three times
-// (statistics; LN-backward sums; write) and the dYn tiles are recomputed in the last walk.
+// K4 backward: dy [T][Cout] -> dx.  dYn = dy W (A = W^T rows = concat channel) -> LayerNorm backward over the kC-long
+// gathered row -> scatter to the 8 (4) source voxels.
+// The two row sums of the LayerNorm backward need no GEMM: with n = gamma*xhat + beta and y = W n (the forward output),
+//     s1 = sum_c dYn_c gamma_c        = dy . (W gamma)
+//     s2 = sum_c dYn_c gamma_c xhat_c = dy . (y - W beta)
+// so they cost O(Cout) per token from dy, the saved forward output y and two weight-only vectors; dYn itself is then
+// formed ONCE, tile by tile, and the tiles are split over gridDim.y (the deep stages have only a few dozen token
+// groups and hundreds of MFMAs per token).
 // ---------------------------------------------------------------------------------------------
 template <int NS>
 __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const bf16_t* __restrict__ dy,
-                                                         const bf16_t* __restrict__ x, const float* __restrict__ ln_w,
-                                                         const float* __restrict__ ln_b, const bf16_t* __restrict__ w_t,
-                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ wg_dn,
-                                                         bf16_t* __restrict__ wg_x) {
+                                                         const bf16_t* __restrict__ x, const bf16_t* __restrict__ yfwd,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         const float* __restrict__ wgam, const float* __restrict__ wbet,
+                                                         const bf16_t* __restrict__ w_t, bf16_t* __restrict__ dx,
+                                                         bf16_t* __restrict__ wg_dn, bf16_t* __restrict__ wg_x) {
     // wg_dn / wg_x (optional, weight-gradient mode): [T][kC] gradient w.r.t. the LayerNorm output and the gathered
     // (front-padded) LayerNorm input rows, the operands of mivp_ln_wgrad / mivp_gemm_tn
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,11 +339,25 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     const MergeTok m = merge_token(d, t);
 
     bf16x8 dyb[NS];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int c = 32 * s + 8 * g;
-        dyb[s] = (m.live && c < Cout) ? ld8(dy + t * Cout + c) : zero8();
+        bf16x8 v = zero8();
+        if (m.live && c < Cout) {
+            v = ld8(dy + t * Cout + c);
+            const bf16x8 yv = ld8(yfwd + t * Cout + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gdy = (float)v[i];
+                s1 += gdy * wgam[c + i];
+                s2 += gdy * ((float)yv[i] - wbet[c + i]);
+            }
+        }
+        dyb[s] = v;
     }
+    const float m1 = col_sum(s1) / (float)kC, m2 = col_sum(s2) / (float)kC;
+
     auto load_x4 = [&](int c0, long& src_out) -> f32x4 {
         f32x4 v = fzero4();
         src_out = -1;
@@ -366,36 +385,18 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     }
     const float rstd = rsqrtf(col_sum(var) / (float)kC + d.ln_eps);
 
-    auto dyn_tile = [&](int ct) -> f32x4 {
-        f32x4 acc = fzero4();
+    const int per_y = (n_ct + gridDim.y - 1) / gridDim.y;
+    const int ct_lo = blockIdx.y * per_y, ct_hi = (ct_lo + per_y) < n_ct ? (ct_lo + per_y) : n_ct;
+    for (int ct = ct_lo; ct < ct_hi; ++ct) {
+        f32x4 gy = fzero4();
         const int row = 16 * ct + r;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int c = 32 * s + 8 * g;
             bf16x8 a = zero8();
             if (row < kC && c < Cout) a = ld8(w_t + (long)row * Cout + c);
-            acc = mfma16(a, dyb[s], acc);
+            gy = mfma16(a, dyb[s], gy);
         }
-        return acc;
-    };
-    float s1 = 0.f, s2 = 0.f;
-    for (int ct = 0; ct < n_ct; ++ct) {
-        const f32x4 gy = dyn_tile(ct);
-        const int c0 = 16 * ct + 4 * g;
-        long so;
-        const f32x4 v = load_x4(c0, so);
-        if (c0 < kC) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dxh = gy[j] * ln_w[c0 + j];
-                s1 += dxh;
-                s2 += dxh * (v[j] - mean) * rstd;
-            }
-        }
-    }
-    const float m1 = col_sum(s1) / (float)kC, m2 = col_sum(s2) / (float)kC;
-    for (int ct = 0; ct < n_ct; ++ct) {
-        const f32x4 gy = dyn_tile(ct);
         const int c0 = 16 * ct + 4 * g;
         long so;
         const f32x4 v = load_x4(c0, so);
@@ -412,19 +413,24 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     }
 }
 
-extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const float* ln_w,
-                                    const float* ln_b, const void* w_t, void* dx, void* wg_dn, void* wg_x,
-                                    mivp_stream_t stream) {
-    MIVP_REQUIRE(d && dy && x && ln_w && ln_b && w_t && dx);
+extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, const void* x, const void* yfwd,
+                                    const float* ln_w, const float* ln_b, const float* wgam, const float* wbet,
+                                    const void* w_t, void* dx, void* wg_dn, void* wg_x, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && dy && x && yfwd && ln_w && ln_b && wgam && wbet && w_t && dx);
     MIVP_REQUIRE((wg_dn == nullptr) == (wg_x == nullptr));
     MIVP_REQUIRE(d->C % 8 == 0 && d->Cout % 8 == 0);
     const int NS = (d->Cout + 31) / 32;
     const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
-    const unsigned grid = (unsigned)((T + 63) / 64);
+    const unsigned gx = (unsigned)((T + 63) / 64);
+    const int kC = (d->merge_last ? 8 : 4) * d->C, n_ct = (kC + 15) / 16;
+    int ny = (int)((1024 + gx - 1) / gx);
+    if (ny > n_ct) ny = n_ct;
+    if (ny < 1) ny = 1;
+    const dim3 grid(gx, (unsigned)ny);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_MB(K) hipLaunchKernelGGL((k_patch_merge_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, \
-                                         (const bf16_t*)x, ln_w, ln_b, (const bf16_t*)w_t, (bf16_t*)dx, (bf16_t*)wg_dn,   \
-                                         (bf16_t*)wg_x)
+#define LAUNCH_MB(K) hipLaunchKernelGGL((k_patch_merge_bwd<K>), grid, dim3(256), 0, st, *d, (const bf16_t*)dy, (const bf16_t*)x, \
+                                         (const bf16_t*)yfwd, ln_w, ln_b, wgam, wbet, (const bf16_t*)w_t, (bf16_t*)dx,            \
+                                         (bf16_t*)wg_dn, (bf16_t*)wg_x)
     switch (NS) {
         case 1: LAUNCH_MB(1); break;
         case 2: LAUNCH_MB(2); break;

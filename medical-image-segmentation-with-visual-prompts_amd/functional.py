@@ -202,21 +202,23 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
 # ----------------------------------------------------------------------------------------------
 class _PatchMergeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, norm_w, norm_b, red_w, ln_w, ln_b, w, w_t, merge_last):
-        ctx.save_for_backward(x, ln_w, ln_b, w_t)
+    def forward(ctx, x, norm_w, norm_b, red_w, ln_w, ln_b, w, w_t, wgam, wbet, merge_last):
+        y = ops.patch_merge(x, ln_w, ln_b, w, merge_last)
+        ctx.save_for_backward(x, ln_w, ln_b, w_t, wgam, wbet, y)
         ctx.merge_last = merge_last
-        return ops.patch_merge(x, ln_w, ln_b, w, merge_last)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, ln_w, ln_b, w_t = ctx.saved_tensors
+        x, ln_w, ln_b, w_t, wgam, wbet, y = ctx.saved_tensors
         g = ctx.needs_input_grad
+        kw = dict(y_fwd=y, wgam=wgam, wbet=wbet)
         if g[1] or g[2] or g[3]:
-            dx, dw, dgamma, dbeta = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last, need_w=True)
+            dx, dw, dgamma, dbeta = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last, need_w=True, **kw)
             return (dx if g[0] else None, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None,
-                    None, None, None, None, None)
-        dx = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last)
-        return dx, None, None, None, None, None, None, None, None
+                    None, None, None, None, None, None, None)
+        dx = ops.patch_merge_backward(dy.contiguous(), x, ln_w, ln_b, w_t, ctx.merge_last, **kw)
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
 def patch_merge(mod, x):
@@ -224,11 +226,13 @@ def patch_merge(mod, x):
 
     def build():
         w = mod.reduction.weight.detach().float()
-        return (mod.norm.weight.detach().float().contiguous(), mod.norm.bias.detach().float().contiguous(),
-                w.to(BF16).contiguous(), w.t().to(BF16).contiguous())
+        ln_w, ln_b = mod.norm.weight.detach().float().contiguous(), mod.norm.bias.detach().float().contiguous()
+        wb = w.to(BF16)
+        wf = wb.float()                                         # the values the kernels multiply with
+        return (ln_w, ln_b, wb.contiguous(), wb.t().contiguous(), (wf @ ln_w).contiguous(), (wf @ ln_b).contiguous())
 
-    ln_w, ln_b, w, w_t = mod._wcache.get("w", params, build)
-    return _PatchMergeFn.apply(x, mod.norm.weight, mod.norm.bias, mod.reduction.weight, ln_w, ln_b, w, w_t,
+    ln_w, ln_b, w, w_t, wgam, wbet = mod._wcache.get("w", params, build)
+    return _PatchMergeFn.apply(x, mod.norm.weight, mod.norm.bias, mod.reduction.weight, ln_w, ln_b, w, w_t, wgam, wbet,
                                mod.merge_last_dim)
 
 

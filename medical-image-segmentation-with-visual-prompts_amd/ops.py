@@ -450,8 +450,9 @@ def add_bf16(a, b):
     return y
 
 
-def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last, need_w=False):
-    """dx, and with ``need_w`` also (d reduction.weight [Cout, kC], d norm.weight, d norm.bias) in f32."""
+def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last, need_w=False, y_fwd=None, wgam=None, wbet=None):
+    """dx, and with ``need_w`` also (d reduction.weight [Cout, kC], d norm.weight, d norm.bias) in f32.
+    y_fwd = the forward output; wgam / wbet = W gamma, W beta (recomputed here when not handed in)."""
     B, H, W, D, Cc = x.shape
     cout = dy.shape[-1]
     d = merge_desc(B, (H, W, D), Cc, cout, merge_last)
@@ -460,8 +461,13 @@ def patch_merge_backward(dy, x, ln_w, ln_b, w_t_bf16, merge_last, need_w=False):
     kC = (8 if merge_last else 4) * Cc
     wg_dn = torch.empty((T, kC), dtype=BF16, device=x.device) if need_w else None
     wg_x = torch.empty((T, kC), dtype=BF16, device=x.device) if need_w else None
-    L.call("mivp_patch_merge_bwd", C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w_t_bf16), L.ptr(dx),
-           L.ptr(wg_dn), L.ptr(wg_x), L.stream())
+    if wgam is None:
+        wf = w_t_bf16.float()                                   # [kC, Cout]
+        wgam, wbet = (ln_w @ wf).contiguous(), (ln_b @ wf).contiguous()
+    if y_fwd is None:
+        y_fwd = patch_merge(x, ln_w, ln_b, w_t_bf16.t().contiguous(), merge_last)
+    L.call("mivp_patch_merge_bwd", C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(y_fwd), L.ptr(ln_w), L.ptr(ln_b), L.ptr(wgam),
+           L.ptr(wbet), L.ptr(w_t_bf16), L.ptr(dx), L.ptr(wg_dn), L.ptr(wg_x), L.stream())
     if not need_w:
         return dx
     from .swin_ops import ln_wgrad
