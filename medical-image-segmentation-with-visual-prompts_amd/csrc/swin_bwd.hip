@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 // Window keys -> dk, dv (bf16); prompt keys -> per-window f32 partials + column sums of dS (the
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int KPW, int NW, bool AUG, bool DROP>
+template <int DKS, int DVT, int KPW, int NW, bool AUG, bool DROP, bool MASKED>
 __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
             if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
             else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
             const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
+            const bool kvalid = kcls != -1;
             bf16x8 kf[DKS];
 #pragma unroll
             for (int s = 0; s < DKS; ++s) {
@@ -565,16 +566,25 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                     const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bool live;
-                        const float sv = classify_logit(s[j], kcls, rqs[j], live);
-                        const bool qok = rqs[j] != -1;                      // padding query rows: no P, no gradient
-                        const float p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
                         float keep = 1.f;
                         if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
                             const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
                             keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                         }
-                        const float dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
+                        float p, dsv;
+                        if (MASKED) {
+                            bool live;
+                            const float sv = classify_logit(s[j], kcls, rqs[j], live);
+                            const bool qok = rqs[j] != -1;                  // padding query rows: no P, no gradient
+                            p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
+                            dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
+                        } else {
+                            // un-shifted block: every valid key is attended by every valid query -- P = 0 exactly where
+                            // either is padding, and dS = P * (...) vanishes with it
+                            const bool ok = kvalid & (rqs[j] != -1);
+                            p = ok ? __builtin_amdgcn_exp2f(s[j] * LOG2E - ls[j]) : 0.f;
+                            dsv = p * (dp[j] * keep - dls[j]);
+                        }
                         pv[hh][j] = p * keep;
                         ds[hh][j] = dsv;
                         dtok[i] += dsv;
@@ -920,7 +930,7 @@ extern "C" int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const 
     return launch_dq<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, d_o, lse, delta, dq, st);
 }
 
-template <int DKS, int DVT, int KPW, bool AUG, bool DROP>
+template <int DKS, int DVT, int KPW, bool AUG, bool DROP, bool MASKED>
 static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp, const void* vp,
                       const void* qa, const void* ka, const int32_t* tok_rid, const void* d_o, const float* lse,
                       const float* delta, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
@@ -937,7 +947,7 @@ static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const
     if (ktiles <= 0) return MIVP_OK;
     constexpr int NW = 8;
     const int ksplit = (ktiles + NW * KPW - 1) / (NW * KPW);
-    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG, DROP>;
+    auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG, DROP, MASKED>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
@@ -962,15 +972,17 @@ extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
 #define DKV_ARGS d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, dka_part, st
-#define DKV_PICK(AUGV, DROPV)                                              \
-    do {                                                                   \
-        if (dks == 1) return launch_dkv<1, 1, 2, AUGV, DROPV>(DKV_ARGS);   \
-        if (dks == 2) return launch_dkv<2, 2, 2, AUGV, DROPV>(DKV_ARGS);   \
-        return launch_dkv<3, 3, 1, AUGV, DROPV>(DKV_ARGS);                 \
+#define DKV_PICK3(AUGV, DROPV, MV)                                              \
+    do {                                                                        \
+        if (dks == 1) return launch_dkv<1, 1, 2, AUGV, DROPV, MV>(DKV_ARGS);    \
+        if (dks == 2) return launch_dkv<2, 2, 2, AUGV, DROPV, MV>(DKV_ARGS);    \
+        return launch_dkv<3, 3, 1, AUGV, DROPV, MV>(DKV_ARGS);                  \
     } while (0)
+#define DKV_PICK(AUGV, DROPV) do { if (d->has_mask) DKV_PICK3(AUGV, DROPV, true); else DKV_PICK3(AUGV, DROPV, false); } while (0)
     if (dka_part) { if (d->attn_drop_thr) DKV_PICK(true, true); else DKV_PICK(true, false); }
     if (d->attn_drop_thr) DKV_PICK(false, true);
     DKV_PICK(false, false);
+#undef DKV_PICK3
 #undef DKV_PICK
 #undef DKV_ARGS
 }
