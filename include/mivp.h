@@ -222,8 +222,9 @@ size_t mivp_conv3d_fwd_ws(const MivpConvDesc* d);
 /* The same convolution for LARGE volumes with few output channels (conv_concat of the last decoder stage,
  * unet_blocks.py:46-56,74): a workgroup stages the 6x10x18 input halo of a 4x8x16 output brick once per
  * 16-channel chunk in LDS instead of fetching every voxel once per tap.
- *   supported: no fused prologue / residual / f32 output, Cin % 16 == 0, Cout % 4 == 0, Cout <= 48
- *   wh: bf16 [Cin/16][14][Cout_p][32]: k-step j = taps (2j, 2j+1) x 16 channels of the chunk, tap 27 = zeros */
+ *   supported: no fused prologue / residual / f32 output, Cin % 16 == 0, Cout % 4 == 0, Cout <= 48 or a multiple of 48
+ *   wh: bf16 [groups][Cin/16][14][BN][32]: groups of 48 output channels (BN = 48, or Cout rounded to 16 when there is
+ *       one group), k-step j = taps (2j, 2j+1) x 16 channels of the chunk, tap 27 = zeros */
 int mivp_conv3d_halo_supported(const MivpConvDesc* d);
 int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias, void* y,
                          mivp_stream_t stream);

@@ -50,6 +50,10 @@ __global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
+    // blockIdx.y = group of BN output channels (convolutions with many output channels re-stage the halo per group:
+    // the halo is small next to the weights); the packed weights are [group][chunk][k-step][BN][32]
+    const int co_base = blockIdx.y * BN;
+    wh += (long)blockIdx.y * (Cin / 16) * (WBYTES / 2);
     const int nbh = (H + HB_H - 1) / HB_H, nbw = (W + HB_W - 1) / HB_W, nbd = (D + HB_D - 1) / HB_D;
     // XCD-aware brick order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of bricks (shared halos in L2)
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const 
             bf16_t* yrow = y + ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                const int co = 16 * nt + 4 * g;
+                const int co = co_base + 16 * nt + 4 * g;
                 if (co < d.Cout) {
                     f32x4 v = acc[i][nt];
                     if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
@@ -179,22 +183,26 @@ __global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const 
 
 }  // namespace
 
-// Shapes the halo kernel takes: Cin a multiple of 16, Cout a multiple of 4 and at most 48 (two halo buffers + two
-// weight buffers of 14 * Cout_p * 64 B must fit the 160 KB of LDS), plain bf16 output with optional bias.  Whether it
-// PAYS (enough bricks to fill 256 CUs) is the caller's call: mivp_amd/ops.py uses it from 512 bricks up.
+// Shapes the halo kernel takes: Cin a multiple of 16, Cout a multiple of 4; up to 48 output channels per workgroup
+// (two halo buffers + two weight buffers of 14 * 48 * 64 B must fit the 160 KB of LDS), more through blockIdx.y groups
+// of 48; plain bf16 output with optional bias.  Whether it PAYS (enough bricks x groups to fill 256 CUs, bricks not
+// mostly padding) is the caller's call: see mivp_amd/ops.py.
 extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
     if (!d || d->pro_affine || d->add_residual || d->out_f32) return 0;
-    if (d->Cin % 16 || d->Cout % 4 || d->Cout > 48 || d->Cout < 1) return 0;
+    if (d->Cin % 16 || d->Cout % 4 || d->Cout < 1) return 0;
+    if (d->Cout > 48 && d->Cout % 48) return 0;
     return 1;
 }
 
-/* wh: bf16 [Cin/16][14][Cout_p][32] with Cout_p = Cout rounded up to 16; element (c, j, co, kk):
- *   kk < 16 : weight[co][16c + kk][tap 2j]      kk >= 16 : weight[co][16c + kk - 16][tap 2j + 1]  (tap 27: zero) */
+/* wh: bf16 [groups][Cin/16][14][BN][32] with BN = 16*ceil(min(Cout, 48)/16), groups = ceil(Cout/48); element
+ * (grp, c, j, co, kk):  kk < 16 : weight[48 grp + co][16c + kk][tap 2j]   kk >= 16 : ...[16c + kk - 16][tap 2j + 1]
+ * (tap 27 and rows past Cout: zero) */
 extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias, void* y,
                                     mivp_stream_t stream) {
     MIVP_REQUIRE(d && x && wh && y);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
-    const int ntn = (d->Cout + 15) / 16;
+    const int groups = (d->Cout + 47) / 48;
+    const int ntn = groups > 1 ? 3 : (d->Cout + 15) / 16;
     const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + HB_W - 1) / HB_W) *
                         ((d->dims[2] + HB_D - 1) / HB_D);
     const size_t lds = 2 * ((size_t)HALO_BYTES + (size_t)KSTEPS * 16 * ntn * 64);
@@ -204,8 +212,8 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
         auto kern = k_conv3d_halo<N>;                                                                                    \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }                              \
-        hipLaunchKernelGGL(kern, dim3((unsigned)bricks), dim3(HTHREADS), lds, st, *d, (const bf16_t*)x, (const bf16_t*)wh, bias, \
-                           (bf16_t*)y);                                                                                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(HTHREADS), lds, st, *d, (const bf16_t*)x, \
+                           (const bf16_t*)wh, bias, (bf16_t*)y);                                                         \
     } while (0)
     if (ntn == 1) HALO_LAUNCH(1);
     else if (ntn == 2) HALO_LAUNCH(2);

@@ -62,17 +62,28 @@ def conv_desc(B, dims, cin, cout, affine, lrelu, residual, out_f32) -> L.ConvDes
     return d
 
 
-def halo_pack(wp: torch.Tensor, cin: int) -> torch.Tensor:
-    """Re-lay the im2col pack [Cout_p][tap*Cin + ci] for the halo-brick kernel: bf16 [Cin/16][14][Cout_p][32] where
-    k-step j holds taps (2j, 2j+1) x 16 channels (tap 27 = zeros).  Cached on the pack tensor (rebuilt with it)."""
+def halo_pack(wp: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
+    """Re-lay the im2col pack [Cout_p][tap*Cin + ci] for the halo-brick kernel: bf16 [groups][Cin/16][14][BN][32] where
+    a group is 48 output channels (BN = 48, or Cout rounded to 16 for a single group) and k-step j holds taps
+    (2j, 2j+1) x 16 channels (tap 27 = zeros).  Cached on the pack tensor (rebuilt with it)."""
     wh = getattr(wp, "_mivp_halo", None)
     if wh is None:
-        cout_p = wp.shape[0]
-        wt = torch.zeros((cout_p, 28, cin), dtype=BF16, device=wp.device)
-        wt[:, :27] = wp[:, :27 * cin].view(cout_p, 27, cin)
-        wh = wt.view(cout_p, 14, 2, cin // 16, 16).permute(3, 1, 0, 2, 4).reshape(cin // 16, 14, cout_p, 32).contiguous()
+        groups = (cout + 47) // 48
+        bn = 48 if groups > 1 else round_up(cout, 16)
+        wt = torch.zeros((groups * bn, 28, cin), dtype=BF16, device=wp.device)
+        rows = min(wp.shape[0], groups * bn)
+        wt[:rows, :27] = wp[:rows, :27 * cin].view(rows, 27, cin)
+        wh = wt.view(groups, bn, 14, 2, cin // 16, 16).permute(0, 4, 2, 1, 3, 5).reshape(groups, cin // 16, 14, bn, 32).contiguous()
         wp._mivp_halo = wh
     return wh
+
+
+def halo_pays(B, dims, cout) -> bool:
+    """Use the halo-brick kernel when bricks x channel groups give every CU work and the bricks are mostly volume."""
+    H, W, D = dims
+    bh, bw, bd = (H + 3) // 4, (W + 7) // 8, (D + 15) // 16
+    fill = (H * W * D) / float(bh * 4 * bw * 8 * bd * 16)
+    return B * bh * bw * bd * ((cout + 47) // 48) >= 200 and fill >= 0.75
 
 
 def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
@@ -82,11 +93,10 @@ def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout
     d = conv_desc(B, (H, W, D), cin, cout, scale is not None, lrelu, residual is not None, out_f32)
     if wp.shape != (round_up(cout, 16), d.Kp):
         raise RuntimeError(f"conv3d: packed weight shape {tuple(wp.shape)} does not match Cout={cout}, Cin={cin}")
-    bricks = B * ((H + 3) // 4) * ((W + 7) // 8) * ((D + 15) // 16)
-    if (force_halo or bricks >= 512) and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
+    if (force_halo or halo_pays(B, (H, W, D), cout)) and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
         # large volume, few output channels: the halo-brick kernel (each input voxel fetched once per workgroup)
         y = torch.empty((B, H, W, D, cout), dtype=BF16, device=x.device)
-        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin)), L.ptr(bias), L.ptr(y), L.stream())
+        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(y), L.stream())
         return y
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))

@@ -32,6 +32,8 @@ def cf(t):       # channels-last device -> [B,C,H,W,D] float cpu
     (144, 48, (9, 13, 21), True),          # dec2 conv_concat channels; ragged bricks on every axis
     (48, 8, (6, 5, 4), False),             # volume smaller than a brick
     (32, 36, (8, 16, 32), True),           # Cout not a multiple of 16
+    (48, 144, (5, 9, 17), True),           # three output-channel groups (dgrad of the dec2 conv)
+    (96, 96, (8, 8, 16), False),           # two groups
 ])
 def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     """The halo-brick form (csrc/conv3d_halo.hip) against F.conv3d and against the im2col kernel on the same input."""
