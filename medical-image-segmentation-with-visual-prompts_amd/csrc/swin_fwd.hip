@@ -387,6 +387,13 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
                                                            const bf16_t* __restrict__ wmlp, const float* __restrict__ bmlp,
                                                            bf16_t* __restrict__ t1_out, bf16_t* __restrict__ y) {
     constexpr int KS = (CT + 1) / 2;
+    // Wide stages (C >= 96) are bound by fetching the weights: every wave used to pull the whole [C][C] matrix through
+    // L1 for its 16 tokens.  There the workgroup's four waves share each 16-row weight slab through LDS (KS sub-tiles of
+    // [16 rows][64 B] in the swizzled operand layout, two slabs in flight: global -> registers one slab ahead).
+    constexpr bool LDSW = CT >= 6;
+    constexpr int PCS = (64 * KS + 255) / 256;                      // 16-byte pieces of a slab per thread
+    __shared__ __attribute__((aligned(16))) char wsm[LDSW ? 2 * KS * 1024 : 16];
+    using WR = OperandRows<32>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
@@ -400,6 +407,24 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     const long b = bp / d.P;
     const int src = live ? tok_src[pw * d.Nqp + slot] : -2;
     const int dst = live ? tok_dst[pw * d.Nqp + slot] : -1;
+    bf16x8 wreg[PCS];
+    auto slab_fetch = [&](const bf16_t* __restrict__ w, int nt) {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
+            const int nrow = 16 * nt + row, c = 32 * sub + 8 * ch;
+            wreg[u] = (p < 64 * KS && nrow < C && c < C) ? ld8(w + (long)nrow * C + c) : zero8();
+        }
+    };
+    auto slab_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
+            if (p < 64 * KS) *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + sub * 1024 + WR::off(row, 8 * ch)) = wreg[u];
+        }
+    };
 
     bf16x8 ob[KS];
 #pragma unroll
@@ -410,16 +435,27 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     // GEMM1: t1 = o Wproj^T + b + shortcut
     f32x4 t1[CT];
     float sum = 0.f;
+    if (LDSW) { slab_fetch(wproj, 0); slab_store(0); __syncthreads(); }
 #pragma unroll
     for (int nt = 0; nt < CT; ++nt) {
         f32x4 acc = fzero4();
         const int nrow = 16 * nt + r;
+        if (LDSW) {
+            if (nt + 1 < CT) slab_fetch(wproj, nt + 1);
+            const char* slab = wsm + (nt & 1) * KS * 1024;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (nrow < C && c < C) a = ld8(wproj + (long)nrow * C + c);
-            acc = mfma16(a, ob[s], acc);
+            for (int s = 0; s < KS; ++s)
+                acc = mfma16(*reinterpret_cast<const bf16x8*>(slab + s * 1024 + WR::off(r, 8 * g)), ob[s], acc);
+            if (nt + 1 < CT) slab_store((nt + 1) & 1);        // that buffer was last read in iteration nt-1
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c = 32 * s + 8 * g;
+                bf16x8 a = zero8();
+                if (nrow < C && c < C) a = ld8(wproj + (long)nrow * C + c);
+                acc = mfma16(a, ob[s], acc);
+            }
         }
         const int n0 = 16 * nt + 4 * g;
         if (n0 < C) {
@@ -471,19 +507,33 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     }
     // GEMM2: t2 = t1 + y2 Wmlp^T + b ; k-step s covers channels 32s..32s+31 in the order
     // kappa = 8g+j' -> channel 32s + 16*(j'>>2) + 4g + (j'&3)
+    if (LDSW) { slab_fetch(wmlp, 0); slab_store(0); __syncthreads(); }     // slab 0 was last read before the final barrier of GEMM1
 #pragma unroll
     for (int mt = 0; mt < CT; ++mt) {
         f32x4 acc = fzero4();
         const int nrow = 16 * mt + r;
+        if (LDSW) {
+            if (mt + 1 < CT) slab_fetch(wmlp, mt + 1);
+            const char* slab = wsm + (mt & 1) * KS * 1024;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x4 lo = zero4(), hi = zero4();
-            const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
-            if (nrow < C) {
-                if (c0 < C) lo = ld4(wmlp + (long)nrow * C + c0);
-                if (c1 < C) hi = ld4(wmlp + (long)nrow * C + c1);
+            for (int s = 0; s < KS; ++s) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(slab + s * 1024 + WR::off(r, 4 * g));
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(slab + s * 1024 + WR::off(r, 16 + 4 * g));
+                acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
             }
-            acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
+            if (mt + 1 < CT) slab_store((mt + 1) & 1);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x4 lo = zero4(), hi = zero4();
+                const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
+                if (nrow < C) {
+                    if (c0 < C) lo = ld4(wmlp + (long)nrow * C + c0);
+                    if (c1 < C) hi = ld4(wmlp + (long)nrow * C + c1);
+                }
+                acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
+            }
         }
         const int n0 = 16 * mt + 4 * g;
         if (n0 < C && dst >= 0) {
