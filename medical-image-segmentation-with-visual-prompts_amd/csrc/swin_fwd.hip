@@ -80,16 +80,54 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
     const int per_split = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int nt_begin = blockIdx.y * per_split;
     const int nt_end = nt_begin + per_split < n_tiles ? nt_begin + per_split : n_tiles;
+    // wide stages (C >= 96): the four waves share each 16-row weight slab through LDS (see k_swin_proj_mlp_fwd)
+    constexpr bool LDSW = KS >= 3;
+    constexpr int PCS = (64 * KS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char wsm[LDSW ? 2 * KS * 1024 : 16];
+    using WR = OperandRows<32>;
+    bf16x8 wreg[PCS];
+    auto slab_fetch = [&](int nt) {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
+            const int nrow = 16 * nt + row, c = 32 * sub + 8 * ch;
+            wreg[u] = (p < 64 * KS && nrow < n_out && c < C) ? ld8(wqkv + (long)nrow * C + c) : zero8();
+        }
+    };
+    auto slab_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
+            if (p < 64 * KS) *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + sub * 1024 + WR::off(row, 8 * ch)) = wreg[u];
+        }
+    };
+    if (LDSW && nt_begin < nt_end) { slab_fetch(nt_begin); slab_store(0); __syncthreads(); }
     for (int nt = nt_begin; nt < nt_end; ++nt) {
         f32x4 acc0 = fzero4(), acc1 = fzero4();
         const int nrow = 16 * nt + r;
+        if (LDSW) {
+            const int cur = (nt - nt_begin) & 1;
+            if (nt + 1 < nt_end) slab_fetch(nt + 1);
+            const char* slab = wsm + cur * KS * 1024;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (nrow < n_out && c < C) a = ld8(wqkv + (long)nrow * C + c);
-            acc0 = mfma16(a, xb[0][s], acc0);
-            acc1 = mfma16(a, xb[1][s], acc1);
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slab + s * 1024 + WR::off(r, 8 * g));
+                acc0 = mfma16(a, xb[0][s], acc0);
+                acc1 = mfma16(a, xb[1][s], acc1);
+            }
+            if (nt + 1 < nt_end) slab_store(cur ^ 1);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c = 32 * s + 8 * g;
+                bf16x8 a = zero8();
+                if (nrow < n_out && c < C) a = ld8(wqkv + (long)nrow * C + c);
+                acc0 = mfma16(a, xb[0][s], acc0);
+                acc1 = mfma16(a, xb[1][s], acc1);
+            }
         }
         const int n0 = 16 * nt + 4 * g;
         if (n0 < n_out) {
