@@ -94,6 +94,42 @@ struct OperandRows {
     }
 };
 
+// Workgroup-shared weight slabs for the token GEMM kernels of the wide stages.  Those kernels are bound by weight
+// fetch: each wave used to pull the whole weight matrix through L1 for its 16 tokens.  A slab is 16 consecutive rows x
+// 32*KSL columns of a row-major bf16 matrix, staged by the 256 threads of the workgroup as KSL sub-tiles of
+// [16 rows][64 B] in the swizzled operand layout (OperandRows<32>); two slabs are in flight (global -> registers one
+// slab ahead, the other buffer was last read one iteration earlier, one barrier per slab).
+template <int KSL>
+struct WeightSlabs {
+    static constexpr int PCS = (64 * KSL + 255) / 256;            // 16-byte pieces per thread
+    static constexpr int BYTES = 2 * KSL * 1024;
+    bf16x8 reg[PCS];
+    // rows row0 .. row0+15 of w (leading dimension ld), zero beyond nrows / ncols
+    MIVP_DEV void fetch(const bf16_t* __restrict__ w, int ld, int row0, int nrows, int ncols) {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            const int sub = p >> 6, row = row0 + ((p & 63) >> 2), col = 32 * sub + 8 * (p & 3);
+            reg[u] = (p < 64 * KSL && row < nrows && col < ncols) ? ld8(w + (long)row * ld + col) : zero8();
+        }
+    }
+    MIVP_DEV void store(char* smem, int buf) const {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int p = threadIdx.x + 256 * u;
+            if (p < 64 * KSL)
+                *reinterpret_cast<bf16x8*>(smem + buf * KSL * 1024 + (p >> 6) * 1024 + OperandRows<32>::off((p & 63) >> 2, 8 * (p & 3))) = reg[u];
+        }
+    }
+    // fragment pieces of row r: 8 elements at column 32*sub + elem (elem multiple of 8) or 4 elements (elem multiple of 4)
+    static MIVP_DEV bf16x8 frag8(const char* smem, int buf, int sub, int r, int elem) {
+        return *reinterpret_cast<const bf16x8*>(smem + buf * KSL * 1024 + sub * 1024 + OperandRows<32>::off(r, elem));
+    }
+    static MIVP_DEV bf16x4 frag4(const char* smem, int buf, int sub, int r, int elem) {
+        return *reinterpret_cast<const bf16x4*>(smem + buf * KSL * 1024 + sub * 1024 + OperandRows<32>::off(r, elem));
+    }
+};
+
 // Deterministic block reduction of per-thread channel-group partials: thread t (global id gt) owns channel group
 // gt % G; its 16 partial sums (8 channels x {s1, s2}) go to LDS and one thread per output channel adds the owners
 // of that group in a fixed order.  (LDS float atomics would be shorter but their order changes run to run, and the

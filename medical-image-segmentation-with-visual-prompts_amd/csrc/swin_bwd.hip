@@ -60,16 +60,29 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
     }
     f32x4 dh[CT], tv[CT];
     float sum = 0.f;
+    constexpr bool LDSW = CT >= 6;                              // wide stages share the weights through LDS (common.hpp)
+    using WS = WeightSlabs<KS>;
+    __shared__ __attribute__((aligned(16))) char wsm[LDSW ? WS::BYTES : 16];
+    WS ws;
+    if (LDSW) { ws.fetch(wmlp_t, C, 0, C, C); ws.store(wsm, 0); __syncthreads(); }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         f32x4 acc = fzero4();
         const int row = 16 * ct + r;
+        if (LDSW) {
+            if (ct + 1 < CT) ws.fetch(wmlp_t, C, 16 * (ct + 1), C, C);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (row < C && c < C) a = ld8(wmlp_t + (long)row * C + c);
-            acc = mfma16(a, dyb[s], acc);
+            for (int s = 0; s < KS; ++s) acc = mfma16(WS::frag8(wsm, ct & 1, s, r, 8 * g), dyb[s], acc);
+            if (ct + 1 < CT) ws.store(wsm, (ct + 1) & 1);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c = 32 * s + 8 * g;
+                bf16x8 a = zero8();
+                if (row < C && c < C) a = ld8(wmlp_t + (long)row * C + c);
+                acc = mfma16(a, dyb[s], acc);
+            }
         }
         dh[ct] = acc;
         const int n0 = 16 * ct + 4 * g;
@@ -132,19 +145,30 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
         }
         g1[ct] = out;
     }
+    if (LDSW) { ws.fetch(wproj_t, C, 0, C, C); ws.store(wsm, 0); __syncthreads(); }    // buffer 0: last read before GEMM A's final barrier
 #pragma unroll
     for (int mt = 0; mt < CT; ++mt) {
         f32x4 acc = fzero4();
         const int row = 16 * mt + r;
+        if (LDSW) {
+            if (mt + 1 < CT) ws.fetch(wproj_t, C, 16 * (mt + 1), C, C);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x4 lo = zero4(), hi = zero4();
-            const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
-            if (row < C) {
-                if (c0 < C) lo = ld4(wproj_t + (long)row * C + c0);
-                if (c1 < C) hi = ld4(wproj_t + (long)row * C + c1);
+            for (int s = 0; s < KS; ++s)
+                acc = mfma16(cat44(WS::frag4(wsm, mt & 1, s, r, 4 * g), WS::frag4(wsm, mt & 1, s, r, 16 + 4 * g)),
+                             cat44(g1[2 * s], g1[2 * s + 1]), acc);
+            if (mt + 1 < CT) ws.store(wsm, (mt + 1) & 1);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x4 lo = zero4(), hi = zero4();
+                const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
+                if (row < C) {
+                    if (c0 < C) lo = ld4(wproj_t + (long)row * C + c0);
+                    if (c1 < C) hi = ld4(wproj_t + (long)row * C + c1);
+                }
+                acc = mfma16(cat44(lo, hi), cat44(g1[2 * s], g1[2 * s + 1]), acc);
             }
-            acc = mfma16(cat44(lo, hi), cat44(g1[2 * s], g1[2 * s + 1]), acc);
         }
         const int n0 = 16 * mt + 4 * g;
         if (ti.live && n0 < C) st4(d_o + ti.tt * (long)C + n0, pack4(acc));
@@ -702,16 +726,29 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
     }
     f32x4 dyv[CT], xv[CT];
     float sum = 0.f;
+    constexpr bool LDSW = CT >= 6;                              // wide stages share the weights through LDS (common.hpp)
+    using WS = WeightSlabs<KS3>;
+    __shared__ __attribute__((aligned(16))) char wsm[LDSW ? WS::BYTES : 16];
+    WS ws;
+    if (LDSW) { ws.fetch(wqkv_t, n3, 0, C, n3); ws.store(wsm, 0); __syncthreads(); }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         f32x4 acc = fzero4();
         const int row = 16 * ct + r;
+        if (LDSW) {
+            if (ct + 1 < CT) ws.fetch(wqkv_t, n3, 16 * (ct + 1), C, n3);
 #pragma unroll
-        for (int s = 0; s < KS3; ++s) {
-            const int n0 = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (row < C && n0 < n3) a = ld8(wqkv_t + (long)row * n3 + n0);
-            acc = mfma16(a, gb[s], acc);
+            for (int s = 0; s < KS3; ++s) acc = mfma16(WS::frag8(wsm, ct & 1, s, r, 8 * g), gb[s], acc);
+            if (ct + 1 < CT) ws.store(wsm, (ct + 1) & 1);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) {
+                const int n0 = 32 * s + 8 * g;
+                bf16x8 a = zero8();
+                if (row < C && n0 < n3) a = ld8(wqkv_t + (long)row * n3 + n0);
+                acc = mfma16(a, gb[s], acc);
+            }
         }
         dyv[ct] = acc;
         const int c0 = 16 * ct + 4 * g;
