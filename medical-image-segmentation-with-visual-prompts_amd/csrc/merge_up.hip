@@ -97,16 +97,19 @@ __global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const 
     const int n_tiles = (d.Cout + 15) / 16;
     const int per_y = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int nt_lo = blockIdx.y * per_y, nt_hi = (nt_lo + per_y) < n_tiles ? (nt_lo + per_y) : n_tiles;
+    // the four waves share each 16-row weight slab through LDS (WeightSlabs, common.hpp): kC is 384 or more here
+    using WS = WeightSlabs<KS>;
+    __shared__ __attribute__((aligned(16))) char wsm[WS::BYTES];
+    WS ws;
+    if (nt_lo < nt_hi) { ws.fetch(w, kC, 16 * nt_lo, d.Cout, kC); ws.store(wsm, 0); __syncthreads(); }
     for (int nt = nt_lo; nt < nt_hi; ++nt) {
         f32x4 acc = fzero4();
-        const int nrow = 16 * nt + r;
+        const int cur = (nt - nt_lo) & 1;
+        if (nt + 1 < nt_hi) ws.fetch(w, kC, 16 * (nt + 1), d.Cout, kC);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (nrow < d.Cout && c < kC) a = ld8(w + (long)nrow * kC + c);
-            acc = mfma16(a, xb[s], acc);
-        }
+        for (int s = 0; s < KS; ++s) acc = mfma16(WS::frag8(wsm, cur, s, r, 8 * g), xb[s], acc);
+        if (nt + 1 < nt_hi) ws.store(wsm, cur ^ 1);
+        __syncthreads();
         const int n0 = 16 * nt + 4 * g;
         if (m.live && n0 < d.Cout) st4(y + t * d.Cout + n0, pack4(acc));
     }
@@ -387,16 +390,19 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
 
     const int per_y = (n_ct + gridDim.y - 1) / gridDim.y;
     const int ct_lo = blockIdx.y * per_y, ct_hi = (ct_lo + per_y) < n_ct ? (ct_lo + per_y) : n_ct;
+    // weight slabs shared by the four waves through LDS (WeightSlabs, common.hpp)
+    using WS = WeightSlabs<NS>;
+    __shared__ __attribute__((aligned(16))) char wsm[WS::BYTES];
+    WS ws;
+    if (ct_lo < ct_hi) { ws.fetch(w_t, Cout, 16 * ct_lo, kC, Cout); ws.store(wsm, 0); __syncthreads(); }
     for (int ct = ct_lo; ct < ct_hi; ++ct) {
         f32x4 gy = fzero4();
-        const int row = 16 * ct + r;
+        const int cur = (ct - ct_lo) & 1;
+        if (ct + 1 < ct_hi) ws.fetch(w_t, Cout, 16 * (ct + 1), kC, Cout);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = 32 * s + 8 * g;
-            bf16x8 a = zero8();
-            if (row < kC && c < Cout) a = ld8(w_t + (long)row * Cout + c);
-            gy = mfma16(a, dyb[s], gy);
-        }
+        for (int s = 0; s < NS; ++s) gy = mfma16(WS::frag8(wsm, cur, s, r, 8 * g), dyb[s], gy);
+        if (ct + 1 < ct_hi) ws.store(wsm, cur ^ 1);
+        __syncthreads();
         const int c0 = 16 * ct + 4 * g;
         long so;
         const f32x4 v = load_x4(c0, so);
