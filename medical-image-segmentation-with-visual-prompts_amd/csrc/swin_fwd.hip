@@ -33,11 +33,12 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
     for (int u = 0; u < 2; ++u) {
         const long t = (tile0 + u) * 16 + r;
         live[u] = t < T;
-        const long tt = live[u] ? t : 0;
-        bp[u] = tt / d.Nqp;
-        slot[u] = (int)(tt - bp[u] * d.Nqp);
-        const int pw = (int)(bp[u] % d.P);
-        const long b = bp[u] / d.P;
+        const unsigned tt = live[u] ? (unsigned)t : 0u;          // T = B*P*Nqp fits 32 bits (checked on the host)
+        const unsigned bpu = tt / (unsigned)d.Nqp;
+        bp[u] = bpu;
+        slot[u] = (int)(tt - bpu * (unsigned)d.Nqp);
+        const int pw = (int)(bpu % (unsigned)d.P);
+        const long b = bpu / (unsigned)d.P;
         const int src = live[u] ? tok_src[pw * d.Nqp + slot[u]] : -2;
         float xs[KS][8];
         float sum = 0.f;
@@ -104,6 +105,9 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
         }
     };
     if (LDSW && nt_begin < nt_end) { slab_fetch(nt_begin); slab_store(0); __syncthreads(); }
+    int o_sel = (16 * nt_begin + 4 * g) / C;
+    int o_head = ((16 * nt_begin + 4 * g) - o_sel * C) / hd;
+    int o_j0 = (16 * nt_begin + 4 * g) - o_sel * C - o_head * hd;
     for (int nt = nt_begin; nt < nt_end; ++nt) {
         f32x4 acc0 = fzero4(), acc1 = fzero4();
         const int nrow = 16 * nt + r;
@@ -131,10 +135,11 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
         }
         const int n0 = 16 * nt + 4 * g;
         if (n0 < n_out) {
-            const int sel = n0 / C;
-            const int cc = n0 - sel * C;
-            const int head = cc / hd;
-            const int j0 = cc - head * hd;
+            // (q|k|v, head, offset in head) of output column n0, carried from tile to tile instead of divided out
+            while (o_j0 >= hd) { o_j0 -= hd; ++o_head; }
+            while (o_head >= d.heads) { o_head -= d.heads; ++o_sel; }
+            const int sel = o_sel, head = o_head, j0 = o_j0;
+            o_j0 += 16;
             bf16_t* base = sel == 0 ? q : (sel == 1 ? k : v);
             const float sc = sel == 0 ? d.q_scale : 1.0f;
             if (live[0]) st4(base + ((bp[0] * d.heads + head) * d.Nqp + slot[0]) * (long)hd + j0, pack4(acc0 * sc));
@@ -590,6 +595,7 @@ static int swin_common_checks(const MivpSwinDesc* d) {
     MIVP_REQUIRE(d->B > 0 && d->C > 0 && d->heads > 0 && d->P > 0);
     MIVP_REQUIRE(d->C % 8 == 0 && d->C % d->heads == 0 && (d->C / d->heads) % 4 == 0);
     MIVP_REQUIRE(d->Nqp % 16 == 0 && d->Nqp >= d->Nq && d->Nqp - d->Nq < 16);
+    MIVP_REQUIRE((long)d->B * d->P * d->Nqp < (1L << 31));      // kernels decode token indices in 32 bits
     MIVP_REQUIRE(d->Npp % 16 == 0 && d->Npp >= d->Np);
     MIVP_REQUIRE(d->Nkp % 32 == 0 && d->Nkp >= d->Nqp + d->Npp);
     MIVP_REQUIRE(d->augp % 4 == 0 && d->augp >= d->aug);
