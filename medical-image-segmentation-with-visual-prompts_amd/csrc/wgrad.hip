@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_gemm_tn_reduce(const float* __restrict
 int tn_splits(const MivpGemmTnDesc* d, int* chunks_per_split) {
     const long nchunks = (d->T + TN_TOK - 1) / TN_TOK;
     const long blocks = (long)((d->M + TN_BLK - 1) / TN_BLK) * ((d->N + TN_BLK - 1) / TN_BLK);
-    long want = (1024 + blocks - 1) / blocks;                 // ~4 WGs per CU over the whole launch
+    long want = (512 + blocks - 1) / blocks;                  // ~2 WGs per CU over the whole launch
     if (want > nchunks) want = nchunks;
     if (want < 1) want = 1;
     const long cps = (nchunks + want - 1) / want;
