@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   keeps the kernel under 128 VGPRs so that 16+ waves per CU hide the LDS / MFMA / exp latency
 //   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int NW, bool DROP>
+template <int DKS, int DVT, int NW, bool DROP, bool ONES>
 __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
@@ -267,6 +267,9 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
     constexpr int DK = 32 * DKS;
     using KR = OperandRows<DK>;
     constexpr int KROW = KR::ROW;                            // bytes
+    // Softmax denominator from the matrix pipe: when the value tile has a spare row (head_dim < 16*DVT) and there is no
+    // dropout, row head_dim of V^T is set to one, so O's row head_dim accumulates sum_k P -- of the same bf16-rounded P
+    // the numerator uses -- and the eight adds per 32 keys leave the (binding) VALU stream.  (ONES is picked at launch.)
     const int Nkp = d.Nkp, Nqp = d.Nqp;
     const int VROW = (Nkp + 8) * 2;                          // bytes
     char* Kimg = smem;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
             if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
             else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
         }
+        if (ONES && c4 == hd4) val[0] = (bf16_t)1.0f;         // V^T row hd = 1: the PV product then also returns sum_k P
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<bf16_t*>(Vt + (size_t)(4 * c4 + i) * VROW + 2 * row) = val[i];
@@ -381,8 +385,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mnew)); sv[hh][j] = p; psum += p; }
-            lsum = lsum * alpha + psum;
+                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mnew)); sv[hh][j] = p; if (!ONES) psum += p; }
+            if (!ONES) lsum = lsum * alpha + psum;
             if (DROP) {                                      // attention dropout acts on P after the softmax sum
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -404,7 +408,17 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                 oacc[dd] = mfma16(a, pb, oacc[dd] * alpha);
             }
         }
-        lsum = col_sum(lsum);
+        if (ONES) {                                          // sum_k P sits in O's row hd: lane (r, g = (hd%16)/4), element hd%4
+            const int dd1 = hd >> 4, e1 = hd & 3, g1 = (hd & 15) >> 2;
+            float pick = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pick = (dd == dd1 && e == e1) ? oacc[dd][e] : pick;
+            lsum = __shfl(pick, r + 16 * g1);
+        } else {
+            lsum = col_sum(lsum);
+        }
         const float inv = (DROP ? d.attn_drop_scale : 1.0f) / lsum;
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) {
@@ -663,7 +677,9 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
-    auto kern = d->attn_drop_thr ? k_win_attn_fwd<DKS, DVT, NW, true> : k_win_attn_fwd<DKS, DVT, NW, false>;
+    const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
+    auto kern = d->attn_drop_thr ? k_win_attn_fwd<DKS, DVT, NW, true, false>
+                                 : (ones ? k_win_attn_fwd<DKS, DVT, NW, false, true> : k_win_attn_fwd<DKS, DVT, NW, false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
