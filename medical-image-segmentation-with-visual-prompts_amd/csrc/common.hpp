@@ -165,4 +165,13 @@ static inline unsigned fixed_group_grid(long items, int G, long cap) {
 void mivp_set_error(const char* msg);
 int mivp_check_launch(const char* what);
 
+// opt a kernel into more than 64 KiB of dynamic LDS; a failure is reported like a failed launch
+#define MIVP_LDS_OPT_IN(kern, bytes)                                                                                          \
+    do {                                                                                                                      \
+        if ((bytes) > 64 * 1024) {                                                                                            \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess) { mivp_set_error(hipGetErrorString(e_)); return MIVP_ELAUNCH; }                             \
+        }                                                                                                                     \
+    } while (0)
+
 #define MIVP_REQUIRE(cond) do { if (!(cond)) { mivp_set_error("contract violated: " #cond); return MIVP_EINVAL; } } while (0)

@@ -564,7 +564,7 @@ extern "C" int mivp_conv3d_wgrad_rows(const MivpConvDesc* d, const void* x, cons
     if (lds > 160 * 1024) { mivp_set_error("conv3d_wgrad_rows: D too long for the LDS row images"); return MIVP_EUNSUPPORTED; }
     const int grid = wgrad_rows_grid(d);
     auto kern = k_conv3d_wgrad_rows;
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MIVP_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x, (const bf16_t*)dy, part);
     rc = mivp_check_launch("conv3d_wgrad_rows");
     if (rc) return rc;

@@ -141,11 +141,11 @@ extern "C" int mivp_head_conv_fwd(const MivpConvDesc* d, const void* x, const fl
     if (rc) return rc;
     if (ks == 1) {
         auto kern = k_head_conv_fwd<1>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MIVP_LDS_OPT_IN(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, *d, (const bf16_t*)x, (const bf16_t*)workspace, bias, y);
     } else {
         auto kern = k_head_conv_fwd<2>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MIVP_LDS_OPT_IN(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, *d, (const bf16_t*)x, (const bf16_t*)workspace, bias, y);
     }
     return mivp_check_launch("head_conv_fwd");

@@ -64,10 +64,7 @@ __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restric
 // sums [B][blocks_per_b][25] -> stats [B][25] (fixed order), loss value
 __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int blocks_per_b, long vol, int C, int c0,
                                       float* __restrict__ stats, float* __restrict__ loss) {
-    __shared__ float dice_sum, focal_sum;
     const int K = 3 * LOSS_MAXC + 1;
-    if (threadIdx.x == 0) { dice_sum = 0.f; focal_sum = 0.f; }
-    __syncthreads();
     // one wave per (b, k) sum: lanes stride over the per-block partials, then a butterfly (fixed order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int used = 3 * C + 1;                                   // columns 0 .. 3C-1 and the focal sum; the rest stay zero

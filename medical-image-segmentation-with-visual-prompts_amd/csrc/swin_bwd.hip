@@ -943,7 +943,7 @@ static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const 
     const int chunk = pick_chunk(nt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
     auto kern = d->attn_drop_thr ? k_win_attn_bwd_dq<DKS, DVT, QPW, NW, true> : k_win_attn_bwd_dq<DKS, DVT, QPW, NW, false>;
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MIVP_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, st, *d, chunk, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,
                        (const bf16_t*)ka, tok_rid, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq);
@@ -985,7 +985,7 @@ static int launch_dkv(const MivpSwinDesc* d, const void* q, const void* k, const
     constexpr int NW = 8;
     const int ksplit = (ktiles + NW * KPW - 1) / (NW * KPW);
     auto kern = k_win_attn_bwd_dkv<DKS, DVT, KPW, NW, AUG, DROP, MASKED>;
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MIVP_LDS_OPT_IN(kern, lds);
     dim3 grid((unsigned)((long)d->B * d->P * d->heads), (unsigned)ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *d, chunk, kt0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (const bf16_t*)d_o,
