@@ -25,22 +25,30 @@
 
 namespace {
 
-constexpr int HB_H = 4, HB_W = 8, HB_D = 16;                  // output brick
-constexpr int HH = HB_H + 2, HW = HB_W + 2, HD = HB_D + 2;    // halo
-constexpr int HROWS = HH * HW * HD;                           // 1080
-constexpr int HALO_BYTES = HROWS * 32;
+// output brick 4 x BW x 16 voxels, BW = 8 (8 waves, 512 voxels) or 4 (4 waves, 256 voxels: the mid-size decoder stages,
+// whose 12- and 24-voxel axes an 8-wide brick would mostly pad); every wave owns 4 tiles of 16 voxels along d
+constexpr int HB_H = 4, HB_D = 16;
+constexpr int HH = HB_H + 2, HD = HB_D + 2;
 constexpr int KSTEPS = 14;                                    // 28 taps (27 + one zero tap) x 16 channels / 32
-constexpr int HTHREADS = 512;
-constexpr int HPIECES = (HROWS * 2 + HTHREADS - 1) / HTHREADS;     // 16-byte halo pieces per thread (5)
+template <int BW>
+struct HaloGeom {
+    static constexpr int HW = BW + 2;
+    static constexpr int HROWS = HH * HW * HD;                 // 1080 (BW 8) / 648 (BW 4)
+    static constexpr int HALO_BYTES = HROWS * 32;
+    static constexpr int THREADS = 64 * BW;
+    static constexpr int HPIECES = (HROWS * 2 + THREADS - 1) / THREADS;   // 16-byte halo pieces per thread
+};
 
 MIVP_DEV int halo_off(int row, int half) { return row * 32 + (half << 4); }
 MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
-template <int NTN>
-__global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
+template <int NTN, int HB_W>
+__global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ wh, const float* __restrict__ bias,
                                                           bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using GEO = HaloGeom<HB_W>;
+    constexpr int HW = GEO::HW, HROWS = GEO::HROWS, HALO_BYTES = GEO::HALO_BYTES, HTHREADS = GEO::THREADS, HPIECES = GEO::HPIECES;
     constexpr int BN = 16 * NTN;
     constexpr int WBYTES = KSTEPS * BN * 64;
     constexpr int WPIECES = (WBYTES / 16 + HTHREADS - 1) / HTHREADS;
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(HTHREADS) void k_conv3d_halo(MivpConvDesc d, const 
     };
 
     // ---- this wave's four voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
-    const int th = wave >> 1, tw0 = (wave & 1) * 4;
+    const int th = HB_W == 8 ? wave >> 1 : wave, tw0 = HB_W == 8 ? (wave & 1) * 4 : 0;
     const int half = g & 1, tsel = g >> 1;
     int vbyte[4];
 #pragma unroll
@@ -198,26 +206,33 @@ extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
  * (grp, c, j, co, kk):  kk < 16 : weight[48 grp + co][16c + kk][tap 2j]   kk >= 16 : ...[16c + kk - 16][tap 2j + 1]
  * (tap 27 and rows past Cout: zero) */
 extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias, void* y,
-                                    mivp_stream_t stream) {
+                                    int32_t brick_w, mivp_stream_t stream) {
     MIVP_REQUIRE(d && x && wh && y);
+    MIVP_REQUIRE(brick_w == 4 || brick_w == 8);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
     const int groups = (d->Cout + 47) / 48;
     const int ntn = groups > 1 ? 3 : (d->Cout + 15) / 16;
-    const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + HB_W - 1) / HB_W) *
+    const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + brick_w - 1) / brick_w) *
                         ((d->dims[2] + HB_D - 1) / HB_D);
-    const size_t lds = 2 * ((size_t)HALO_BYTES + (size_t)KSTEPS * 16 * ntn * 64);
+    const size_t halo_bytes = brick_w == 8 ? HaloGeom<8>::HALO_BYTES : HaloGeom<4>::HALO_BYTES;
+    const size_t lds = 2 * (halo_bytes + (size_t)KSTEPS * 16 * ntn * 64);
     hipStream_t st = (hipStream_t)stream;
-#define HALO_LAUNCH(N)                                                                                                   \
+#define HALO_LAUNCH(N, W)                                                                                                \
     do {                                                                                                                 \
-        auto kern = k_conv3d_halo<N>;                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }                              \
-        hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(HTHREADS), lds, st, *d, (const bf16_t*)x, \
+        auto kern = k_conv3d_halo<N, W>;                                                                                 \
+        MIVP_LDS_OPT_IN(kern, lds);                                                                                      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(64 * W), lds, st, *d, (const bf16_t*)x,  \
                            (const bf16_t*)wh, bias, (bf16_t*)y);                                                         \
     } while (0)
-    if (ntn == 1) HALO_LAUNCH(1);
-    else if (ntn == 2) HALO_LAUNCH(2);
-    else HALO_LAUNCH(3);
+    if (brick_w == 8) {
+        if (ntn == 1) HALO_LAUNCH(1, 8);
+        else if (ntn == 2) HALO_LAUNCH(2, 8);
+        else HALO_LAUNCH(3, 8);
+    } else {
+        if (ntn == 1) HALO_LAUNCH(1, 4);
+        else if (ntn == 2) HALO_LAUNCH(2, 4);
+        else HALO_LAUNCH(3, 4);
+    }
 #undef HALO_LAUNCH
     return mivp_check_launch("conv3d_halo_fwd");
 }

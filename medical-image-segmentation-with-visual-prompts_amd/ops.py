@@ -78,25 +78,35 @@ def halo_pack(wp: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
     return wh
 
 
-def halo_pays(B, dims, cout) -> bool:
-    """Use the halo-brick kernel when bricks x channel groups give every CU work and the bricks are mostly volume."""
+def halo_brick(B, dims, cout) -> int:
+    """Brick width (8 or 4) for the halo-brick kernel, 0 for the im2col kernel (tiny volumes).  One 128-155 KB workgroup
+    fits a CU and every wave does the same work at either width, so the cost model is rounds = ceil(workgroups / 256);
+    ties go to the narrow brick (more, smaller workgroups fill the chip better).  Measured on the four decoder shapes
+    (tools/bench_conv.py): the halo kernel beats im2col on all of them, 8 wins at 48^3 / 24^3 / 12x12x24, 4 at 6x6x24."""
     H, W, D = dims
-    bh, bw, bd = (H + 3) // 4, (W + 7) // 8, (D + 15) // 16
-    fill = (H * W * D) / float(bh * 4 * bw * 8 * bd * 16)
-    return B * bh * bw * bd * ((cout + 47) // 48) >= 200 and fill >= 0.75
+    if B * H * W * D < 1024:
+        return 0
+    groups = (cout + 47) // 48
+    rounds = {}
+    for bw in (8, 4):
+        wgs = B * ((H + 3) // 4) * ((W + bw - 1) // bw) * ((D + 15) // 16) * groups
+        rounds[bw] = (wgs + 255) // 256
+    return 8 if rounds[8] < rounds[4] else 4
 
 
 def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, lrelu: bool = False,
-           residual: Optional[torch.Tensor] = None, out_f32: bool = False, force_halo: bool = False) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, out_f32: bool = False, force_halo=False) -> torch.Tensor:
     B, H, W, D, cin = x.shape
     d = conv_desc(B, (H, W, D), cin, cout, scale is not None, lrelu, residual is not None, out_f32)
     if wp.shape != (round_up(cout, 16), d.Kp):
         raise RuntimeError(f"conv3d: packed weight shape {tuple(wp.shape)} does not match Cout={cout}, Cin={cin}")
-    if (force_halo or halo_pays(B, (H, W, D), cout)) and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
+    bw = int(force_halo) if force_halo not in (False, True) else (8 if force_halo else halo_brick(B, (H, W, D), cout))
+    if bw and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
         # large volume, few output channels: the halo-brick kernel (each input voxel fetched once per workgroup)
         y = torch.empty((B, H, W, D, cout), dtype=BF16, device=x.device)
-        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(y), L.stream())
+        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(y),
+               C.c_int32(bw), L.stream())
         return y
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))

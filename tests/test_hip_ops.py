@@ -45,12 +45,13 @@ def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     want = F.conv3d(x, w, b, padding=1)
     wp = ops.pack_conv_weight(w.to(DEV))
     bd = None if b is None else b.to(DEV)
-    y = ops.conv3d(cl(x), wp, bd, cout, force_halo=True)
+    y = ops.conv3d(cl(x), wp, bd, cout, force_halo=8)
+    y4 = ops.conv3d(cl(x), wp, bd, cout, force_halo=4)      # 4x4x16 bricks, 4 waves
     y_ref = ops.conv3d(cl(x), wp, bd, cout)                 # few bricks -> the im2col kernel
     torch.cuda.synchronize()
     assert getattr(wp, "_mivp_halo", None) is not None     # the halo path really ran
-    assert rel_l2(cf(y), want) < 4e-3
-    assert rel_l2(cf(y), cf(y_ref)) < 2e-3
+    assert rel_l2(cf(y), want) < 4e-3 and rel_l2(cf(y4), want) < 4e-3
+    assert rel_l2(cf(y), cf(y_ref)) < 2e-3 and rel_l2(cf(y4), cf(y_ref)) < 2e-3
 
 
 @pytest.mark.parametrize("cin,cout,dims,affine,lrelu,res,f32", [

@@ -9,6 +9,7 @@ SH = {"headf": (48, 2, (96, 96, 96), True), "dec2": (144, 48, (48, 48, 48), True
       "bott": (384, 384, (6, 6, 24), False), "head": (48, 2, (96, 96, 96), True)}
 name = sys.argv[1] if len(sys.argv) > 1 else "dec2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+halo = int(sys.argv[3]) if len(sys.argv) > 3 else None      # 8 / 4: force that brick width, 0: force the im2col kernel
 cin, cout, dims, aff = SH[name]
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(0)
@@ -24,7 +25,14 @@ for it in range(iters + 2):
     if name == "headf":
         y = ops.head_conv(x, w, b, torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
     else:
-        y = ops.conv3d(x, wp, b, cout, scale, shift, aff and name != "head", None, name == "head")
+        if halo is None:
+            y = ops.conv3d(x, wp, b, cout, scale, shift, aff and name != "head", None, name == "head")
+        elif halo == 0:
+            ops.halo_brick_saved = getattr(ops, "halo_brick_saved", ops.halo_brick)
+            ops.halo_brick = lambda *a: 0
+            y = ops.conv3d(x, wp, b, cout, scale, shift, aff and name != "head", None, name == "head")
+        else:
+            y = ops.conv3d(x, wp, b, cout, force_halo=halo)
 t1.record(); torch.cuda.synchronize()
 ms = t0.elapsed_time(t1) / iters
 fl = 2.0 * 27 * cin * cout * 4 * dims[0] * dims[1] * dims[2]
