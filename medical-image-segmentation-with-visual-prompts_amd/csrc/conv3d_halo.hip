@@ -45,7 +45,7 @@ MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 template <int NTN, int HB_W>
 __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ wh, const float* __restrict__ bias,
-                                                          bf16_t* __restrict__ y) {
+                                                          const bf16_t* __restrict__ residual, bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GEO = HaloGeom<HB_W>;
     constexpr int HW = GEO::HW, HROWS = GEO::HROWS, HALO_BYTES = GEO::HALO_BYTES, HTHREADS = GEO::THREADS, HPIECES = GEO::HPIECES;
@@ -175,13 +175,15 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
     for (int i = 0; i < 4; ++i) {
         const int gh = h0 + th, gw = w0 + tw0 + i, gd = d0 + r;
         if (gh < H && gw < W && gd < D) {
-            bf16_t* yrow = y + ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
+            const long vox_off = ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
+            bf16_t* yrow = y + vox_off;
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
                 const int co = co_base + 16 * nt + 4 * g;
                 if (co < d.Cout) {
                     f32x4 v = acc[i][nt];
                     if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
+                    if (residual) { const bf16x4 rv = ld4(residual + vox_off + co); for (int j = 0; j < 4; ++j) v[j] += (float)rv[j]; }
                     st4(yrow + co, pack4(v));
                 }
             }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
 // of 48; plain bf16 output with optional bias.  Whether it PAYS (enough bricks x groups to fill 256 CUs, bricks not
 // mostly padding) is the caller's call: see mivp_amd/ops.py.
 extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
-    if (!d || d->pro_affine || d->add_residual || d->out_f32) return 0;
+    if (!d || d->pro_affine || d->out_f32) return 0;
     if (d->Cin % 16 || d->Cout % 4 || d->Cout < 1) return 0;
     if (d->Cout > 48 && d->Cout % 48) return 0;
     return 1;
@@ -205,9 +207,10 @@ extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
 /* wh: bf16 [groups][Cin/16][14][BN][32] with BN = 16*ceil(min(Cout, 48)/16), groups = ceil(Cout/48); element
  * (grp, c, j, co, kk):  kk < 16 : weight[48 grp + co][16c + kk][tap 2j]   kk >= 16 : ...[16c + kk - 16][tap 2j + 1]
  * (tap 27 and rows past Cout: zero) */
-extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias, void* y,
-                                    int32_t brick_w, mivp_stream_t stream) {
+extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias,
+                                    const void* residual, void* y, int32_t brick_w, mivp_stream_t stream) {
     MIVP_REQUIRE(d && x && wh && y);
+    MIVP_REQUIRE((d->add_residual != 0) == (residual != nullptr));
     MIVP_REQUIRE(brick_w == 4 || brick_w == 8);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
     const int groups = (d->Cout + 47) / 48;
@@ -222,7 +225,7 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
         auto kern = k_conv3d_halo<N, W>;                                                                                 \
         MIVP_LDS_OPT_IN(kern, lds);                                                                                      \
         hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(64 * W), lds, st, *d, (const bf16_t*)x,  \
-                           (const bf16_t*)wh, bias, (bf16_t*)y);                                                         \
+                           (const bf16_t*)wh, bias, (const bf16_t*)residual, (bf16_t*)y);                                \
     } while (0)
     if (brick_w == 8) {
         if (ntn == 1) HALO_LAUNCH(1, 8);

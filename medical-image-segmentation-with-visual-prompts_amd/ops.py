@@ -105,8 +105,8 @@ def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout
     if bw and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
         # large volume, few output channels: the halo-brick kernel (each input voxel fetched once per workgroup)
         y = torch.empty((B, H, W, D, cout), dtype=BF16, device=x.device)
-        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(y),
-               C.c_int32(bw), L.stream())
+        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(residual),
+               L.ptr(y), C.c_int32(bw), L.stream())
         return y
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))

@@ -42,12 +42,14 @@ def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     x = r16(torch.randn(2, cin, *dims, generator=g))
     w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5)
     b = torch.randn(cout, generator=g) * 0.1 if bias else None
-    want = F.conv3d(x, w, b, padding=1)
+    res = r16(torch.randn(2, cout, *dims, generator=g)) if cin == cout else None      # bottleneck-style residual
+    want = F.conv3d(x, w, b, padding=1) + (res if res is not None else 0)
     wp = ops.pack_conv_weight(w.to(DEV))
     bd = None if b is None else b.to(DEV)
-    y = ops.conv3d(cl(x), wp, bd, cout, force_halo=8)
-    y4 = ops.conv3d(cl(x), wp, bd, cout, force_halo=4)      # 4x4x16 bricks, 4 waves
-    y_ref = ops.conv3d(cl(x), wp, bd, cout)                 # few bricks -> the im2col kernel
+    rd = None if res is None else cl(res)
+    y = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=8)
+    y4 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=4)      # 4x4x16 bricks, 4 waves
+    y_ref = ops.conv3d(cl(x), wp, bd, cout, residual=rd)    # tiny volume -> the im2col kernel
     torch.cuda.synchronize()
     assert getattr(wp, "_mivp_halo", None) is not None     # the halo path really ran
     assert rel_l2(cf(y), want) < 4e-3 and rel_l2(cf(y4), want) < 4e-3
