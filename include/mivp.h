@@ -222,11 +222,12 @@ size_t mivp_conv3d_fwd_ws(const MivpConvDesc* d);
 /* The same convolution for LARGE volumes with few output channels (conv_concat of the last decoder stage,
  * unet_blocks.py:46-56,74): a workgroup stages the 6x10x18 (6x6x18) input halo of a 4x8x16 (4x4x16) output brick once per
  * 16-channel chunk in LDS instead of fetching every voxel once per tap.
- *   supported: no fused prologue / f32 output, Cin % 16 == 0, Cout % 4 == 0, Cout <= 48 or a multiple of 48
+ *   supported: bf16 output, Cin % 16 == 0, Cout % 4 == 0, Cout <= 48 or a multiple of 48
  *   wh: bf16 [groups][Cin/16][14][BN][32]: groups of 48 output channels (BN = 48, or Cout rounded to 16 when there is
  *       one group), k-step j = taps (2j, 2j+1) x 16 channels of the chunk, tap 27 = zeros */
 int mivp_conv3d_halo_supported(const MivpConvDesc* d);
 int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias,
+                         const float* scale, const float* shift /* prologue, NULL unless d->pro_affine */,
                          const void* residual /* NULL unless d->add_residual */, void* y, int32_t brick_w /* 8: 4x8x16 bricks, 8 waves; 4: 4x4x16 bricks, 4 waves */, mivp_stream_t stream);
 /* Segmentation-head forward (swin_unetr.py:229-237): y = conv3x3x3(x * scale + shift) + bias for 27*Cout <= 64
  * (Cout <= 2), Cin + 1 <= 64.  x [B,H,W,D,Cin] bf16 (pre-BatchNorm), w f32 [Cout][Cin][3][3][3] (the nn.Conv3d

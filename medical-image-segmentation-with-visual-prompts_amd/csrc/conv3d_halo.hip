@@ -45,6 +45,7 @@ MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 template <int NTN, int HB_W>
 __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ wh, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const bf16_t* __restrict__ residual, bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GEO = HaloGeom<HB_W>;
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
     constexpr int WPIECES = (WBYTES / 16 + HTHREADS - 1) / HTHREADS;
     auto Hs = [&](int buf) -> char* { return smem + buf * (HALO_BYTES + WBYTES); };
     auto Ws = [&](int buf) -> char* { return smem + buf * (HALO_BYTES + WBYTES) + HALO_BYTES; };
+    // optional prologue (BatchNorm affine + LeakyReLU of the layer in front, unet_blocks.py:41-45,74): applied ONCE per
+    // staged input piece -- not once per tap as in the im2col kernel -- and only to voxels inside the volume (the conv's
+    // zero padding comes after the activation).  scale | shift live behind the tile buffers: [2][Cin] f32.
+    float* aff = reinterpret_cast<float*>(smem + 2 * (HALO_BYTES + WBYTES));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -91,10 +96,16 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
         }
     }
     const int nchunks = Cin / 16;
+    if (d.pro_affine) {
+        for (int c = tid; c < Cin; c += HTHREADS) { aff[c] = scale[c]; aff[Cin + c] = shift[c]; }
+        __syncthreads();
+    }
     bf16x8 hreg[HPIECES], wreg[WPIECES];
+    int fetched_chunk = 0;
     auto fetch = [&](int c) {
 #pragma unroll
         for (int u = 0; u < HPIECES; ++u) hreg[u] = hsrc[u] >= 0 ? ld8(x + hsrc[u] + 16 * c) : zero8();
+        fetched_chunk = c;
         const bf16_t* wsrc = wh + (long)c * (WBYTES / 2);
 #pragma unroll
         for (int u = 0; u < WPIECES; ++u) {
@@ -106,8 +117,20 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
         char* hs = Hs(buf);
         char* ws = Ws(buf);
 #pragma unroll
-        for (int u = 0; u < HPIECES; ++u)
-            if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(hs + hdst[u]) = hreg[u];
+        for (int u = 0; u < HPIECES; ++u) {
+            if (hdst[u] < 0) continue;
+            bf16x8 v = hreg[u];
+            if (d.pro_affine && hsrc[u] >= 0) {
+                const int c0 = 16 * fetched_chunk + 8 * ((tid + HTHREADS * u) & 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float f = (float)v[i] * aff[c0 + i] + aff[Cin + c0 + i];
+                    if (d.pro_lrelu) f = f > 0.f ? f : 0.01f * f;
+                    v[i] = (bf16_t)f;
+                }
+            }
+            *reinterpret_cast<bf16x8*>(hs + hdst[u]) = v;
+        }
 #pragma unroll
         for (int u = 0; u < WPIECES; ++u) {
             const int p = tid + HTHREADS * u;
@@ -198,7 +221,8 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
 // of 48; plain bf16 output with optional bias.  Whether it PAYS (enough bricks x groups to fill 256 CUs, bricks not
 // mostly padding) is the caller's call: see mivp_amd/ops.py.
 extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
-    if (!d || d->pro_affine || d->out_f32) return 0;
+    if (!d || d->out_f32) return 0;
+    if (d->pro_affine && d->Cin > 1024) return 0;
     if (d->Cin % 16 || d->Cout % 4 || d->Cout < 1) return 0;
     if (d->Cout > 48 && d->Cout % 48) return 0;
     return 1;
@@ -208,8 +232,10 @@ extern "C" int mivp_conv3d_halo_supported(const MivpConvDesc* d) {
  * (grp, c, j, co, kk):  kk < 16 : weight[48 grp + co][16c + kk][tap 2j]   kk >= 16 : ...[16c + kk - 16][tap 2j + 1]
  * (tap 27 and rows past Cout: zero) */
 extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias,
-                                    const void* residual, void* y, int32_t brick_w, mivp_stream_t stream) {
+                                    const float* scale, const float* shift, const void* residual, void* y, int32_t brick_w,
+                                    mivp_stream_t stream) {
     MIVP_REQUIRE(d && x && wh && y);
+    MIVP_REQUIRE(!d->pro_affine || (scale && shift));
     MIVP_REQUIRE((d->add_residual != 0) == (residual != nullptr));
     MIVP_REQUIRE(brick_w == 4 || brick_w == 8);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
@@ -218,14 +244,15 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + brick_w - 1) / brick_w) *
                         ((d->dims[2] + HB_D - 1) / HB_D);
     const size_t halo_bytes = brick_w == 8 ? HaloGeom<8>::HALO_BYTES : HaloGeom<4>::HALO_BYTES;
-    const size_t lds = 2 * (halo_bytes + (size_t)KSTEPS * 16 * ntn * 64);
+    const size_t lds = 2 * (halo_bytes + (size_t)KSTEPS * 16 * ntn * 64) + (d->pro_affine ? (size_t)2 * d->Cin * sizeof(float) : 0);
+    if (lds > 160 * 1024) { mivp_set_error("conv3d_halo_fwd: LDS budget exceeded"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
 #define HALO_LAUNCH(N, W)                                                                                                \
     do {                                                                                                                 \
         auto kern = k_conv3d_halo<N, W>;                                                                                 \
         MIVP_LDS_OPT_IN(kern, lds);                                                                                      \
         hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(64 * W), lds, st, *d, (const bf16_t*)x,  \
-                           (const bf16_t*)wh, bias, (const bf16_t*)residual, (bf16_t*)y);                                \
+                           (const bf16_t*)wh, bias, scale, shift, (const bf16_t*)residual, (bf16_t*)y);                  \
     } while (0)
     if (brick_w == 8) {
         if (ntn == 1) HALO_LAUNCH(1, 8);

@@ -304,8 +304,7 @@ class _BnActConvFn(torch.autograd.Function):
         if out_f32 and not lrelu and ops.head_conv_supported(x.shape[-1], cout):
             y = ops.head_conv(x, conv_w, conv_b, scale, shift)          # segmentation head: fused BN-affine + conv
         else:
-            xa = ops.affine_act(x, scale, shift, lrelu)
-            y = ops.conv3d(xa, wp, conv_b.detach().float().contiguous(), cout, None, None, False, None, out_f32)
+            y = ops.conv3d_bn_act(x, wp, conv_b.detach().float().contiguous(), cout, scale, shift, lrelu, out_f32)
         ctx.save_for_backward(x, scale, shift, mean_rstd)
         ctx.meta = (bn.training, lrelu, wd, cout, x.shape[-1])
         ctx.conv_w = conv_w

@@ -94,6 +94,20 @@ def halo_brick(B, dims, cout) -> int:
     return 8 if rounds[8] < rounds[4] else 4
 
 
+def conv3d_bn_act(x, wp, bias, cout, scale, shift, lrelu, out_f32=False, fuse_prologue=False):
+    """conv3x3x3(act(x * scale + shift)).  Default: one elementwise pass applies the BatchNorm affine + activation and
+    the conv streams plain operands.  The halo-brick kernel can also apply the prologue while staging its input
+    (``fuse_prologue``; tested): at the decoder shapes that saves the 18 us pass but costs the MFMA-bound conv 12 us,
+    a wash end to end, so the product keeps the conv kernel clean.  (Fused into the im2col kernel the prologue would be
+    re-applied per tap -- ~100 VALU ops per k-step -- which is why it was split off in the first place.)"""
+    if fuse_prologue and not out_f32:
+        B, H, W, D, cin = x.shape
+        d = conv_desc(B, (H, W, D), cin, cout, True, lrelu, False, out_f32)
+        if halo_brick(B, (H, W, D), cout) and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
+            return conv3d(x, wp, bias, cout, scale, shift, lrelu, None, False)
+    return conv3d(affine_act(x, scale, shift, lrelu), wp, bias, cout, None, None, False, None, out_f32)
+
+
 def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, lrelu: bool = False,
            residual: Optional[torch.Tensor] = None, out_f32: bool = False, force_halo=False) -> torch.Tensor:
@@ -105,8 +119,8 @@ def conv3d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout
     if bw and L.lib().mivp_conv3d_halo_supported(C.byref(d)):
         # large volume, few output channels: the halo-brick kernel (each input voxel fetched once per workgroup)
         y = torch.empty((B, H, W, D, cout), dtype=BF16, device=x.device)
-        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(residual),
-               L.ptr(y), C.c_int32(bw), L.stream())
+        L.call("mivp_conv3d_halo_fwd", C.byref(d), L.ptr(x), L.ptr(halo_pack(wp, cin, cout)), L.ptr(bias), L.ptr(scale),
+               L.ptr(shift), L.ptr(residual), L.ptr(y), C.c_int32(bw), L.stream())
         return y
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     ws_bytes = L.lib().mivp_conv3d_fwd_ws(C.byref(d))

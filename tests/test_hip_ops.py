@@ -56,6 +56,26 @@ def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     assert rel_l2(cf(y), cf(y_ref)) < 2e-3 and rel_l2(cf(y4), cf(y_ref)) < 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,dims,lrelu,bw", [(144, 48, (9, 13, 21), True, 8), (32, 96, (6, 6, 24), False, 4)])
+def test_conv3d_halo_fused_prologue(cin, cout, dims, lrelu, bw):
+    """BatchNorm affine (+ LeakyReLU) applied while the halo is staged: zero padding stays zero AFTER the activation."""
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cin + bw)
+    x = r16(torch.randn(2, cin, *dims, generator=g))
+    w = r16(torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    scale, shift = 1 + 0.2 * torch.randn(cin, generator=g), 0.2 * torch.randn(cin, generator=g)
+    xin = x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    if lrelu:
+        xin = F.leaky_relu(xin, 0.01)
+    want = F.conv3d(r16(xin), w, b, padding=1)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    y = ops.conv3d(cl(x), wp, b.to(DEV), cout, scale.to(DEV), shift.to(DEV), lrelu, force_halo=bw)
+    torch.cuda.synchronize()
+    assert getattr(wp, "_mivp_halo", None) is not None
+    assert rel_l2(cf(y), want) < 4e-3
+
+
 @pytest.mark.parametrize("cin,cout,dims,affine,lrelu,res,f32", [
     (16, 16, (5, 6, 7), False, False, False, False),
     (24, 48, (6, 6, 8), True, True, False, False),      # Cin % 32 != 0: k-steps straddle taps
