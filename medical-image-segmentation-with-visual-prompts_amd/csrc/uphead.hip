@@ -48,11 +48,17 @@ MIVP_DEV float gram_w(int p, int m, int n) {                 // (U^T U)[p][p+m] 
     return ((unsigned)(p + m) < (unsigned)n) ? 0.375f : 0.f;
 }
 
+// The stencil is separable: A[d] = sum_{m0,m1} g0 g1 x[p0+m0, p1+m1, d] (nine loads), then
+// q[d] = g2(-1) A[d-1] + g2(0) A[d] + g2(+1) A[d+1].  A thread owns a (b, p0, p1, 8-channel group) line and slides
+// along a segment of d keeping the last three A's: 9 loads per cell instead of 27.  Lines are cut into segments of
+// ST_SEG cells for parallelism (the two A's beyond a segment's ends are recomputed).
+constexpr int ST_SEG = 16;
 __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__ x, int B, int h, int w, int d, int C,
                                                       float* __restrict__ part) {
     __shared__ float lds[256 * 16];
     const int G = C / 8;
-    const long T = (long)B * h * w * d, items = T * G;
+    const int nseg = (d + ST_SEG - 1) / ST_SEG;
+    const long items = (long)B * h * w * nseg * G;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     const int cg = (int)(gtid % G);
@@ -60,36 +66,57 @@ __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
     for (long it = gtid; it < items; it += stride) {
-        const long p = it / G;
-        const int p2 = (int)(p % d);
-        long rest = p / d;
+        long rest = it / G;
+        const int seg = (int)(rest % nseg);
+        rest /= nseg;
         const int p1 = (int)(rest % w);
         rest /= w;
         const int p0 = (int)(rest % h);
-        const bf16_t* xp = x + p * C + cg * 8;
-        const bf16x8 cv = ld8(xp);
-        float xc[8], q[8];
+        const long b = rest / h;
+        const int lo = seg * ST_SEG, hi = (lo + ST_SEG) < d ? (lo + ST_SEG) : d;
+        float g01[3][3];
+        long roff[3][3];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { xc[i] = (float)cv[i]; q[i] = 0.f; s1[i] += 8.f * xc[i]; }
+        for (int m0 = 0; m0 < 3; ++m0)
 #pragma unroll
-        for (int m0 = -1; m0 <= 1; ++m0) {
-            const float g0 = gram_w(p0, m0, h);
+            for (int m1 = 0; m1 < 3; ++m1) {
+                g01[m0][m1] = gram_w(p0, m0 - 1, h) * gram_w(p1, m1 - 1, w);
+                const int q0 = g01[m0][m1] != 0.f ? p0 + m0 - 1 : p0, q1 = g01[m0][m1] != 0.f ? p1 + m1 - 1 : p1;
+                roff[m0][m1] = (((b * h + q0) * w + q1) * (long)d) * C + cg * 8;
+            }
+        float Am[8], Ac[8], xc[8];                 // A[dd-1], A[dd] and the centre value x[dd] while A[dd+1] is formed
 #pragma unroll
-            for (int m1 = -1; m1 <= 1; ++m1) {
-                const float g01 = g0 * gram_w(p1, m1, w);
+        for (int i = 0; i < 8; ++i) { Am[i] = 0.f; Ac[i] = 0.f; xc[i] = 0.f; }
+        for (int dd = lo - 1; dd <= hi; ++dd) {    // A[dd] for dd = lo-1 .. hi; cell dd-1 is completed when A[dd] arrives
+            float An[8], xn[8];
 #pragma unroll
-                for (int m2 = -1; m2 <= 1; ++m2) {
-                    const float gg = g01 * gram_w(p2, m2, d);
-                    if (gg != 0.f) {                             // zero only for neighbours outside the volume
-                        const bf16x8 nv = ld8(xp + (((long)m0 * w + m1) * d + m2) * C);
+            for (int i = 0; i < 8; ++i) { An[i] = 0.f; xn[i] = 0.f; }
+            if (dd >= 0 && dd < d) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) q[i] += gg * (float)nv[i];
+                for (int m0 = 0; m0 < 3; ++m0)
+#pragma unroll
+                    for (int m1 = 0; m1 < 3; ++m1) {
+                        const bf16x8 v = ld8(x + roff[m0][m1] + (long)dd * C);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) An[i] += g01[m0][m1] * (float)v[i];
+                        if (m0 == 1 && m1 == 1) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) xn[i] = (float)v[i];
+                        }
                     }
+            }
+            const int cell = dd - 1;               // its three A's are Am (cell-1), Ac (cell), An (cell+1)
+            if (cell >= lo && cell < hi) {
+                const float gm = gram_w(cell, -1, d), g0 = gram_w(cell, 0, d), gp = gram_w(cell, 1, d);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s1[i] += 8.f * xc[i];
+                    s2[i] += xc[i] * (gm * Am[i] + g0 * Ac[i] + gp * An[i]);
                 }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s2[i] += xc[i] * q[i];
+            for (int i = 0; i < 8; ++i) { Am[i] = Ac[i]; Ac[i] = An[i]; xc[i] = xn[i]; }
+        }
     }
     block_reduce_groups(lds, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
 }
@@ -442,7 +469,8 @@ static int uphead_checks(int B, int h, int w, int d, int C, int Cout) {
 }
 
 extern "C" int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w, int32_t d, int32_t C) {
-    return (int)fixed_group_grid((long)B * h * w * d * (C / 8), C / 8, 2048);
+    const int nseg = (d + ST_SEG - 1) / ST_SEG;
+    return (int)fixed_group_grid((long)B * h * w * nseg * (C / 8), C / 8, 2048);
 }
 
 extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
