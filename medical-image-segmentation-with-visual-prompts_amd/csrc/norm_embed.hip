@@ -31,6 +31,14 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    // single-channel volumes (the CT configurations): the thread's 8 x 8 weights live in registers for its whole walk
+    float wreg[8][8];
+    if (Cin == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wreg[i][k] = wl[(cg * 8 + i) * 8 + k];
+    }
     for (long it = gtid; it < items; it += stride) {
         const long vox = it / G;
         const long b = vox / ovol;
@@ -42,6 +50,17 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
+        if (Cin == 1) {
+            const float* xb = x + b * ivol;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const float2 xv = *reinterpret_cast<const float2*>(xb + ((long)(2 * h + a) * W + (2 * ww + bb)) * D + 2 * z);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += xv.x * wreg[i][a * 4 + bb * 2] + xv.y * wreg[i][a * 4 + bb * 2 + 1];
+                }
+        } else
         for (int ci = 0; ci < Cin; ++ci) {
             const float* xb = x + (b * Cin + ci) * ivol;
 #pragma unroll
