@@ -309,6 +309,8 @@ typedef struct MivpUpcatDesc {
     int32_t scale[3];           /* 1 or 2 per axis                                     */
     int32_t Cx;                 /* channels of the low-res tensor                      */
     int32_t Cs;                 /* channels of the skip tensor (0 = no concat)         */
+    int32_t align_corners;      /* 0: half-pixel centres (output_layer, SwinUpBlock); 1: align_corners=True  */
+                                /*    (the reconstruction head's nn.Upsample, swin_unetr.py:199-201)          */
 } MivpUpcatDesc;
 /* x [B,ih,iw,id,Cx] bf16, skip [B,oh,ow,od,Cs] bf16 -> y [B,oh,ow,od,Cx+Cs] bf16 */
 int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void* y, mivp_stream_t stream);
@@ -396,6 +398,18 @@ int mivp_ln_wgrad(const void* x, const int32_t* tok_src, const void* dn, int64_t
 size_t mivp_gemm_tn_ws(const MivpGemmTnDesc* d);   /* fp32 split partials */
 int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* b, void* workspace, size_t ws_bytes,
                  float* out, mivp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* 1x1x1 convolution with <= 4 output channels (last layer of the            */
+/* reconstruction head, swin_unetr.py:204-209)                               */
+/* ------------------------------------------------------------------------ */
+/* y [n_vox][Cout] f32 = bias + x [n_vox][C] bf16 . w [Cout][C] f32 */
+int mivp_pointwise_fwd(const void* x, const float* w, const float* bias, int64_t n_vox, int32_t C, int32_t Cout,
+                       float* y, mivp_stream_t stream);
+/* dx [n_vox][C] bf16 = dy [n_vox][Cout] f32 . w;  dyb (optional) [n_vox][4] bf16 = dy zero-padded: the A operand of
+ * mivp_gemm_tn for the weight gradient */
+int mivp_pointwise_bwd(const float* dy, const float* w, int64_t n_vox, int32_t C, int32_t Cout, void* dx, void* dyb,
+                       mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* small utilities                                                          */

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -39,7 +39,8 @@ class EmbedDesc(C.Structure):
 
 
 class UpcatDesc(C.Structure):
-    _fields_ = [("B", i32), ("idims", i32 * 3), ("odims", i32 * 3), ("scale", i32 * 3), ("Cx", i32), ("Cs", i32)]
+    _fields_ = [("B", i32), ("idims", i32 * 3), ("odims", i32 * 3), ("scale", i32 * 3), ("Cx", i32), ("Cs", i32),
+                ("align_corners", i32)]
 
 
 class OperandDesc(C.Structure):

@@ -156,12 +156,18 @@ extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const
 // ---------------------------------------------------------------------------------------------
 struct Lerp { int i0, i1; float w0, w1; };
 
-MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in) {
+MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in, int align = 0) {
     Lerp l;
     if (scale == 1) { l.i0 = l.i1 = o; l.w0 = 1.f; l.w1 = 0.f; return l; }
-    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
-    if (src < 0.f) src = 0.f;
+    float src;
+    if (align) {                                              // align_corners=True: o * (n_in - 1) / (n_out - 1), n_out = 2 n_in
+        src = (float)o * ((float)(n_in - 1) / (float)(2 * n_in - 1));
+    } else {
+        src = ((float)o + 0.5f) * 0.5f - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
     l.i0 = (int)src;
+    if (l.i0 > n_in - 1) l.i0 = n_in - 1;
     l.i1 = l.i0 + (l.i0 < n_in - 1 ? 1 : 0);
     l.w1 = src - (float)l.i0;
     l.w0 = 1.f - l.w1;
@@ -180,8 +186,8 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
     const int boh = row / OW;
     const int oh = boh % d.odims[0];
     const int b = boh / d.odims[0];
-    const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0]);
-    const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1]);
+    const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0], d.align_corners);
+    const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1], d.align_corners);
     const long in_row = (long)d.idims[2] * d.Cx;
     const bf16_t* r00 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i0) * in_row;
     const bf16_t* r01 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i1) * in_row;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
             st8(yrow + od * Ct + cg * 8, ld8(srow + od * d.Cs + (cg - Gx) * 8));
             continue;
         }
-        const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2]);
+        const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2], d.align_corners);
         const int o0 = ld.i0 * d.Cx + cg * 8, o1 = ld.i1 * d.Cx + cg * 8;
         const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
         const bf16x8 c0 = ld8(r10 + o0), c1 = ld8(r10 + o1), e0 = ld8(r11 + o0), e1 = ld8(r11 + o1);
@@ -244,17 +250,18 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16
         const int iw = (int)(rem / d.idims[2]);
         const int id = (int)(rem - (long)iw * d.idims[2]);
         const int ic[3] = {ih, iw, id};
-        int cand[3][4];
-        float cw[3][4];
+        int cand[3][8];
+        float cw[3][8];
         int ncand[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             ncand[a] = 0;
-            const int lo = d.scale[a] == 1 ? ic[a] : 2 * ic[a] - 1;
-            const int hi = d.scale[a] == 1 ? ic[a] : 2 * ic[a] + 2;
+            // outputs whose two-point stencil can touch input ic: 2i-1 .. 2i+2 (half-pixel centres), 2i-2 .. 2i+4 (align_corners)
+            const int lo = d.scale[a] == 1 ? ic[a] : 2 * ic[a] - (d.align_corners ? 2 : 1);
+            const int hi = d.scale[a] == 1 ? ic[a] : 2 * ic[a] + (d.align_corners ? 4 : 2);
             for (int o = lo; o <= hi; ++o) {
                 if (o < 0 || o >= d.odims[a]) continue;
-                const Lerp l = lerp_axis(o, d.scale[a], d.idims[a]);
+                const Lerp l = lerp_axis(o, d.scale[a], d.idims[a], d.align_corners);
                 float wgt = 0.f;
                 if (l.i0 == ic[a]) wgt += l.w0;
                 if (l.i1 == ic[a]) wgt += l.w1;

@@ -402,17 +402,84 @@ def uphead(bn, conv, x):
 # ----------------------------------------------------------------------------------------------
 class _UpcatFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, skip, scale):
-        ctx.meta = (tuple(x.shape[1:4]), tuple(scale), x.shape[-1], 0 if skip is None else skip.shape[-1])
-        return ops.upcat(x, skip, scale)
+    def forward(ctx, x, skip, scale, align_corners):
+        ctx.meta = (tuple(x.shape[1:4]), tuple(scale), x.shape[-1], 0 if skip is None else skip.shape[-1], align_corners)
+        return ops.upcat(x, skip, scale, align_corners=align_corners)
 
     @staticmethod
     def backward(ctx, dy):
-        idims, scale, cx, cs = ctx.meta
+        idims, scale, cx, cs, align = ctx.meta
         dx, dskip = ops.upcat_backward(dy.contiguous(), idims, scale, cx, cs,
-                                       need_skip=cs > 0 and ctx.needs_input_grad[1])
-        return (dx if ctx.needs_input_grad[0] else None), dskip, None
+                                       need_skip=cs > 0 and ctx.needs_input_grad[1], align_corners=align)
+        return (dx if ctx.needs_input_grad[0] else None), dskip, None, None
 
 
-def upcat(x, skip, scale):
-    return _UpcatFn.apply(x, skip, tuple(int(s) for s in scale))
+def upcat(x, skip, scale, align_corners=False):
+    return _UpcatFn.apply(x, skip, tuple(int(s) for s in scale), bool(align_corners))
+
+
+# ----------------------------------------------------------------------------------------------
+# phase-1 proxy heads (--training-mode self_supervised_learning_encoder, swin_unetr.py:64-83,180-222)
+# ----------------------------------------------------------------------------------------------
+class _InstanceNormActFn(torch.autograd.Function):
+    """nn.InstanceNorm3d (no affine) + nn.LeakyReLU(0.01) on channels-last bf16."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, saved = ops.instance_norm_act(x, eps, True)
+        ctx.save_for_backward(x)
+        ctx.saved = saved
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.instance_norm_act_backward(x, dy.contiguous(), ctx.saved, True), None
+
+
+class _PointwiseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return ops.pointwise_conv(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.pointwise_conv_backward(x, w, dy, ctx.needs_input_grad[0])
+        return dx, dw.reshape(w.shape) if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.global_avg_pool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, D, Cc = ctx.shape
+        g = (dy / float(H * W * D)).to(BF16)
+        return g.view(B, 1, 1, 1, Cc).expand(B, H, W, D, Cc).contiguous()
+
+
+def reconstruction_head(owner, head: torch.nn.Sequential, x):
+    """[Conv3d 3^3 -> InstanceNorm3d -> LeakyReLU -> Upsample(trilinear, align_corners=True)] x (depth+1) -> Conv3d 1^3
+    (swin_unetr.py:185-212) on the deepest encoder feature; returns f32 channels-last [B,H,W,D,input_channels]."""
+    mods = list(head)
+    i = 0
+    stage = 0
+    while i + 3 < len(mods):
+        conv, norm, act, up = mods[i:i + 4]
+        x = conv3d_plain(owner, f"rec{stage}", conv, x)
+        x = _InstanceNormActFn.apply(x, float(norm.eps))
+        x = upcat(x, None, tuple(int(s) for s in up.scale_factor), align_corners=True)
+        i += 4
+        stage += 1
+    last = mods[i]
+    return _PointwiseConvFn.apply(x, last.weight, last.bias)
+
+
+def pooled_linear(linear: torch.nn.Linear, x):
+    """AdaptiveAvgPool3d((1,1,1)) -> Linear (rotation / contrastive heads, swin_unetr.py:72-81); the [B, C] matmul is torch's."""
+    return torch.nn.functional.linear(_GlobalAvgPoolFn.apply(x), linear.weight, linear.bias)

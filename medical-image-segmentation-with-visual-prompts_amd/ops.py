@@ -439,15 +439,16 @@ def patch_merge(x, ln_w, ln_b, w_bf16, merge_last):
 # ------------------------------------------------------------------------------------------
 # trilinear upsample + crop + concat
 # ------------------------------------------------------------------------------------------
-def upcat_desc(B, idims, odims, scale, cx, cs) -> L.UpcatDesc:
+def upcat_desc(B, idims, odims, scale, cx, cs, align_corners=False) -> L.UpcatDesc:
     d = L.UpcatDesc()
     d.B, d.Cx, d.Cs = B, cx, cs
+    d.align_corners = 1 if align_corners else 0
     for a in range(3):
         d.idims[a], d.odims[a], d.scale[a] = int(idims[a]), int(odims[a]), int(scale[a])
     return d
 
 
-def upcat(x, skip, scale: Sequence[int], odims: Optional[Sequence[int]] = None):
+def upcat(x, skip, scale: Sequence[int], odims: Optional[Sequence[int]] = None, align_corners: bool = False):
     B, ih, iw, id_, cx = x.shape
     if skip is not None:
         odims = skip.shape[1:4]
@@ -455,16 +456,16 @@ def upcat(x, skip, scale: Sequence[int], odims: Optional[Sequence[int]] = None):
     else:
         cs = 0
         odims = odims or (ih * scale[0], iw * scale[1], id_ * scale[2])
-    d = upcat_desc(B, (ih, iw, id_), odims, scale, cx, cs)
+    d = upcat_desc(B, (ih, iw, id_), odims, scale, cx, cs, align_corners)
     y = torch.empty((B, odims[0], odims[1], odims[2], cx + cs), dtype=BF16, device=x.device)
     L.call("mivp_upcat_fwd", C.byref(d), L.ptr(x), L.ptr(skip), L.ptr(y), L.stream())
     return y
 
 
-def upcat_backward(dy, idims, scale, cx, cs, need_skip=True):
+def upcat_backward(dy, idims, scale, cx, cs, need_skip=True, align_corners=False):
     B = dy.shape[0]
     odims = dy.shape[1:4]
-    d = upcat_desc(B, idims, odims, scale, cx, cs)
+    d = upcat_desc(B, idims, odims, scale, cx, cs, align_corners)
     dx = torch.empty((B, idims[0], idims[1], idims[2], cx), dtype=BF16, device=dy.device)
     dskip = torch.empty((B, odims[0], odims[1], odims[2], cs), dtype=BF16, device=dy.device) if (cs and need_skip) else None
     L.call("mivp_upcat_bwd", C.byref(d), L.ptr(dy), L.ptr(dx), L.ptr(dskip), L.stream())
@@ -563,3 +564,64 @@ def gemm_tn(a: torch.Tensor, a_desc: L.OperandDesc, b: torch.Tensor, b_desc: L.O
     ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
     L.call("mivp_gemm_tn", C.byref(d), L.ptr(a), L.ptr(b), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(out), L.stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# pieces of the phase-1 proxy heads (swin_unetr.py:64-83,180-222)
+# ---------------------------------------------------------------------------------------------
+def pointwise_conv(x, w, bias):
+    """1x1x1 conv, <= 4 output channels: x bf16 [B,H,W,D,C], w [Cout, C(,1,1,1)] -> f32 [B,H,W,D,Cout]."""
+    B, H, W, D, Cc = x.shape
+    cout = w.shape[0]
+    wf = w.detach().float().reshape(cout, Cc).contiguous()
+    y = torch.empty((B, H, W, D, cout), dtype=torch.float32, device=x.device)
+    L.call("mivp_pointwise_fwd", L.ptr(x), L.ptr(wf), L.ptr(None if bias is None else bias.detach().float().contiguous()),
+           C.c_int64(B * H * W * D), C.c_int32(Cc), C.c_int32(cout), L.ptr(y), L.stream())
+    return y
+
+
+def pointwise_conv_backward(x, w, dy, need_dx=True):
+    """(dx bf16, dW [Cout, C], db [Cout]) of pointwise_conv; dy f32 [B,H,W,D,Cout]."""
+    B, H, W, D, Cc = x.shape
+    cout = w.shape[0]
+    n = B * H * W * D
+    wf = w.detach().float().reshape(cout, Cc).contiguous()
+    dy = dy.contiguous().float()
+    dx = torch.empty_like(x)
+    dyb = torch.empty((n, 4), dtype=BF16, device=x.device)
+    L.call("mivp_pointwise_bwd", L.ptr(dy), L.ptr(wf), C.c_int64(n), C.c_int32(Cc), C.c_int32(cout), L.ptr(dx), L.ptr(dyb),
+           L.stream())
+    dw = gemm_tn(dyb, operand_rows(4), x, operand_rows(Cc), n, cout, Cc)
+    db = dy.view(n, cout).sum(0)
+    return (dx if need_dx else None), dw, db
+
+
+def instance_norm_act(x, eps=1e-5, lrelu=True):
+    """nn.InstanceNorm3d (no affine, batch statistics per sample) + LeakyReLU(0.01): the per-sample form of the training
+    BatchNorm kernels.  Returns (y, saved) with saved = per-sample (scale, shift, mean_rstd)."""
+    B, Cc = x.shape[0], x.shape[-1]
+    one = torch.ones(Cc, dtype=torch.float32, device=x.device)
+    zero = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    saved = []
+    for b in range(B):
+        scale, shift, mean_rstd = bn_batch_stats(x[b:b + 1], one, zero, eps)
+        y[b:b + 1] = affine_act(x[b:b + 1], scale, shift, lrelu)
+        saved.append((scale, shift, mean_rstd))
+    return y, saved
+
+
+def instance_norm_act_backward(x, dy, saved, lrelu=True):
+    dx = torch.empty_like(x)
+    for b, (scale, shift, mean_rstd) in enumerate(saved):
+        dxb, _, _ = bn_backward(x[b:b + 1], dy[b:b + 1].contiguous(), scale, shift, mean_rstd, lrelu)
+        dx[b:b + 1] = dxb
+    return dx
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool3d((1,1,1)) on channels-last bf16: f32 [B, C]."""
+    from .swin_ops import _colsum_bf16
+    B, Cc = x.shape[0], x.shape[-1]
+    n = x.numel() // (B * Cc)
+    return torch.stack([_colsum_bf16(x[b].reshape(n, Cc)) for b in range(B)]) / float(n)

@@ -421,12 +421,17 @@ class SwinUnetR(nn.Module):
         return out
 
     def _encoder_outputs(self, feats):
-        c = self.conf
+        """forward_ssl_encoder (swin_unetr.py:64-83): the feature list plus the configured proxy-task heads on the deepest
+        feature."""
         out = {}
-        if any(k in self.extra_heads for k in ("reconstruction", "rotation_prediction", "contrastive_coding")):
-            raise NotImplementedError(
-                "mivp_amd: the phase-1 proxy-task heads (reconstruction / rotation / contrastive, swin_unetr.py:185-222) "
-                "are outside the hot path built so far; construct the model with those flags off")
+        deepest = feats[0]
+        if "reconstruction" in self.extra_heads:
+            rec = Fn.reconstruction_head(self, self.extra_heads["reconstruction"], deepest)
+            out["reconstruction"] = Fn.to_channels_first(rec)
+        if "rotation_prediction" in self.extra_heads:
+            out["rotation_prediction"] = Fn.pooled_linear(self.extra_heads["rotation_prediction"], deepest)
+        if "contrastive_coding" in self.extra_heads:
+            out["contrastive_coding"] = Fn.pooled_linear(self.extra_heads["contrastive_coding"], deepest)
         out["out_vit"] = [Fn.to_channels_first(f) if f.dim() == 5 and f.dtype == torch.bfloat16 else f for f in feats]
         return out
 

@@ -381,3 +381,32 @@ def test_single_rank_ddp_step_on_rccl():
         assert train.max_over_ranks(1.5, torch.device("cuda", 0)) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_ssl_encoder_mode_with_proxy_heads():
+    """--training-mode self_supervised_learning_encoder with the three phase-1 proxy heads (swin_unetr.py:64-83,180-222):
+    the dict keys and shapes of the reference, a backward through all of them, finite gradients for every parameter of
+    the reference's encoder partition."""
+    import mivp_amd
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, _, _ = train.make_conf("tiny")
+    conf.training_mode = "self_supervised_learning_encoder"
+    conf.use_encoder_prompting = conf.use_decoder_prompting = False
+    conf.use_reconstruction = conf.use_rotation_prediction = conf.use_contrastive_learning = True
+    conf.contrastive_coding_dim = 32
+    torch.manual_seed(0)
+    model = SwinUnetR(conf).to(DEV).train()
+    x = torch.rand(2, 1, 32, 32, 32, device=DEV)
+    out = model(x)
+    assert set(out) == {"reconstruction", "rotation_prediction", "contrastive_coding", "out_vit"}
+    assert out["reconstruction"].shape == (2, 1, 32, 32, 32)
+    assert out["rotation_prediction"].shape == (2, 4) and out["contrastive_coding"].shape == (2, 32)
+    assert len(out["out_vit"]) == conf.depth_unet + 2
+    loss = out["reconstruction"].float().pow(2).mean() + out["rotation_prediction"].pow(2).mean() + out["contrastive_coding"].pow(2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    enc = model.named_parameters_encoder()
+    assert len(enc) > 100
+    for n, p in enc:
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n

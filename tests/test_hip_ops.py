@@ -343,3 +343,124 @@ def test_uphead_low_resolution_head(C, cout, dims, training):
         assert rel_l2(bn2.running_mean.cpu(), bn.running_mean) < 2e-3
         assert rel_l2(bn2.running_var.cpu(), bn.running_var) < 2e-3
         assert int(bn2.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+def test_reconstruction_head_matches_torch_modules():
+    """The phase-1 reconstruction head (swin_unetr.py:185-212): [Conv3d 3^3 -> InstanceNorm3d -> LeakyReLU ->
+    Upsample(trilinear, align_corners=True)] x 4 -> Conv3d 1^3 are stock torch modules, so torch itself is the oracle:
+    forward, input gradient and every parameter gradient on a small deepest-feature tensor.
+    Tolerances: output 1e-2 (four bf16 stages incl. instance norms on few voxels); gradients against a measured
+    bf16-storage yardstick (see below)."""
+    import copy
+    import torch.nn as nn
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    chs = [64, 32, 16, 16, 16]
+    layers = []
+    for i in range(4):
+        layers += [nn.Conv3d(chs[i], chs[i + 1], 3, 1, 1), nn.InstanceNorm3d(chs[i + 1]), nn.LeakyReLU(),
+                   nn.Upsample(scale_factor=(2, 2, 1 if i < 2 else 2), mode="trilinear", align_corners=True)]
+    layers.append(nn.Conv3d(chs[-1], 2, 1, 1))
+    head = nn.Sequential(*layers)
+    with torch.no_grad():
+        for m in head:
+            if isinstance(m, nn.Conv3d):
+                m.weight.copy_(r16(m.weight))
+    x = r16(torch.randn(2, 64, 4, 4, 6, generator=g)).requires_grad_(True)
+    y = head(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+
+    class Owner:
+        pass
+    owner = Owner()
+    owner._wcache = Fn.WeightCache()
+    head2 = copy.deepcopy(head).to(DEV)
+    for p in head2.parameters():
+        p.grad = None
+    xd = cl(x.detach()).requires_grad_(True)
+    out = Fn.reconstruction_head(owner, head2, xd)
+    out.backward(dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (2, 64, 64, 24, 2) == tuple(y.permute(0, 2, 3, 4, 1).shape) and out.dtype == torch.float32
+    assert rel_l2(out.detach().cpu().permute(0, 4, 1, 2, 3), y.detach()) < 1e-2
+    errs = {"dx": rel_l2(cf(xd.grad), x.grad)}
+    for (n1, p1), (n2, p2) in zip(head.named_parameters(), head2.named_parameters()):
+        if n1.endswith(".bias") and n1 != "16.bias":         # conv bias in front of an instance norm: true gradient zero
+            assert float(p2.grad.abs().max()) < 2e-2 * float(dict(head2.named_parameters())[n1.replace("bias", "weight")].grad.abs().max()), n1
+            continue
+        errs[n1] = rel_l2(p2.grad.cpu(), p1.grad)
+    # Yardstick: the same torch chain in fp32 with every stage boundary (conv output, activation, upsample) rounded to
+    # bf16 in both directions - the storage precision of the HIP path.  The instance norms' backward projects out the
+    # mean and the xhat component, so the surviving gradients are differences of much larger terms and a 2^-9 rounding
+    # shows up as 4-8 % in the deepest gradients of this chain (measured, seed 3); the HIP path has to stay within
+    # 1.25x that yardstick, and within 1e-2 where the yardstick itself is small.
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return r16(t)
+
+        @staticmethod
+        def backward(ctx, gr):
+            return r16(gr)
+
+    class _RoundM(nn.Module):
+        def forward(self, t):
+            return _Round.apply(t)
+
+    mods = []
+    for m in copy.deepcopy(head):
+        mods.append(m)
+        if isinstance(m, (nn.Conv3d, nn.LeakyReLU, nn.Upsample)):
+            mods.append(_RoundM())
+    head_r = nn.Sequential(*mods)
+    for p in head_r.parameters():
+        p.grad = None
+    xr = x.detach().clone().requires_grad_(True)
+    head_r(xr).backward(dy)
+    yard = {"dx": rel_l2(xr.grad, x.grad)}
+    wn = [n for n, _ in head.named_parameters()]
+    for n, pr in zip(wn, head_r.parameters()):
+        if n in errs:
+            yard[n] = rel_l2(pr.grad, dict(head.named_parameters())[n].grad)
+    for k, e in errs.items():
+        assert e < max(1.25 * yard[k], 1e-2), (k, e, yard[k], errs, yard)
+
+
+def test_pooled_linear_heads():
+    import copy
+    import torch.nn as nn
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(4)
+    x = r16(torch.randn(2, 64, 3, 3, 6, generator=g)).requires_grad_(True)
+    lin = nn.Linear(64, 4)
+    y = lin(nn.AdaptiveAvgPool3d((1, 1, 1))(x).flatten(1))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    lin2 = copy.deepcopy(lin).to(DEV)
+    for p in lin2.parameters():
+        p.grad = None
+    xd = cl(x.detach()).requires_grad_(True)
+    out = Fn.pooled_linear(lin2, xd)
+    out.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(out.detach().cpu(), y.detach()) < 1e-5
+    assert rel_l2(cf(xd.grad), x.grad) < 4e-3
+    assert rel_l2(lin2.weight.grad.cpu(), lin.weight.grad) < 1e-5
+
+
+@pytest.mark.parametrize("scale,dims", [((2, 2, 1), (3, 4, 5)), ((2, 2, 2), (2, 3, 4)), ((2, 2, 2), (1, 1, 3))])
+def test_upsample_align_corners(scale, dims):
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(dims[0])
+    x = r16(torch.randn(2, 16, *dims, generator=g)).requires_grad_(True)
+    want = F.interpolate(x, scale_factor=tuple(float(s) for s in scale), mode="trilinear", align_corners=True)
+    dy = r16(torch.randn(want.shape, generator=g))
+    want.backward(dy)
+    y = ops.upcat(cl(x.detach()), None, scale, align_corners=True)
+    dx, _ = ops.upcat_backward(cl(dy), dims, scale, 16, 0, align_corners=True)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(y), want.detach()) < 4e-3
+    assert rel_l2(cf(dx), x.grad) < 4e-3
