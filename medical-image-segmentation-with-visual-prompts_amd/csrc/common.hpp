@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/mivp.h"
 
 typedef __bf16 bf16_t;
@@ -46,6 +47,12 @@ MIVP_DEV bf16x8 cat44(bf16x4 lo, bf16x4 hi) {
 // sum / max over the 4 lanes that share a token column (lanes r, r+16, r+32, r+48)
 MIVP_DEV float col_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 MIVP_DEV float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v; }
+// IEEE-754-2019 maximum (gfx950: v_maximum3_f32): unlike fmaxf() it needs no canonicalisation of its operands -- fmaxf()
+// on an MFMA result or a cross-lane read costs an extra `v_max x, x` per operand because the compiler cannot prove the
+// value is not a signalling NaN; in the VALU-bound softmax loops that is one wasted op per logit.  max3_raw folds two
+// inputs per instruction.
+MIVP_DEV float max2_raw(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+MIVP_DEV float max3_raw(float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 
 // Attention logit classes (branch-free: these compile to v_cmp + v_cndmask, never to exec-mask branches).
 //   key class  -1: padding key, excluded from the softmax (logit -> -inf)

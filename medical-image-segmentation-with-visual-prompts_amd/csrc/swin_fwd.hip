@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   keeps the kernel under 128 VGPRs so that 16+ waves per CU hide the LDS / MFMA / exp latency
 //   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int NW, bool DROP, bool ONES>
+template <int DKS, int DVT, int NW, bool DROP, bool ONES, bool MASKED>
 __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
     // ---- key classes (classify_logit in common.hpp) ----
     for (int m = tid; m < Nkp; m += 64 * NW) {
         int cls = -1;
-        if (m < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + m] : 0;
+        if (m < d.Nq) cls = MASKED ? tok_rid[pw * Nqp + m] : 0;
         else if (m >= Nqp && m < Nqp + d.Np) cls = -2;
         ridk[m] = cls;
     }
@@ -323,10 +323,11 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
     const int npairs = Nkp / 32;                             // key tiles come in pairs (Nkp % 32 == 0)
     const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
     const float LOG2E = 1.4426950408889634f;
+    constexpr float RESCALE_LOG2 = 8.f;
 
     for (int qt = wave; qt < Nqp / 16; qt += NW) {
         const int qrow = qt * 16 + r;
-        const int rq = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        const int rq = (MASKED && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
         // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
         bf16x8 qf[DKS];
 #pragma unroll
@@ -348,7 +349,14 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
         float mrun = -INFINITY, lsum = 0.f;                  // mrun already multiplied by log2(e)
         const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
 
-        for (int u = 0; u < npairs; ++u) {
+        // One step = 32 keys.  TAIL steps hold padding / prompt keys and classify every logit; the others only apply
+        // the shift mask (MASKED).  The running max is refreshed lazily: only when some query of the wave sees a logit
+        // more than RESCALE_LOG2 above its reference point are O (and the sum) rescaled, otherwise P is formed against
+        // the older reference (P <= 2^RESCALE_LOG2, exact after the final division) -- the exp, the subtract and the
+        // O multiplies leave the VALU stream for almost every step.  max3 / max2 are raw v_max instructions: fmaxf()
+        // makes the compiler canonicalise each MFMA result first (one extra VALU op per logit).
+        auto step = [&](int u, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
             f32x4 sv[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -357,8 +365,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
                 for (int s = 0; s < DKS; ++s)
                     acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * t + r, 32 * s + 8 * g)), qf[s], acc);
-                if (t < nt_full) {
-                    if (d.has_mask) {
+                if (!TAIL || t < nt_full) {
+                    if (MASKED) {
                         const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
                         acc[0] = (kr.x == rq) ? acc[0] : 0.f;
                         acc[1] = (kr.y == rq) ? acc[1] : 0.f;
@@ -375,18 +383,27 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                 }
                 sv[hh] = acc;                                // natural-log units; log2(e) rides on the fma below
             }
-            float pmax = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
-                               fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
-            pmax = col_max(pmax) * LOG2E;
-            const float mnew = fmaxf(mrun, pmax);            // the first pair always holds valid content keys: finite
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            mrun = mnew;
+            float pmax = max3_raw(sv[0][0], sv[0][1], sv[0][2]);
+            pmax = max3_raw(pmax, sv[0][3], sv[1][0]);
+            pmax = max3_raw(pmax, sv[1][1], sv[1][2]);
+            pmax = max2_raw(pmax, sv[1][3]);
+            pmax = max2_raw(pmax, __shfl_xor(pmax, 16));
+            pmax = max2_raw(pmax, __shfl_xor(pmax, 32));
+            if (__any(fmaf(pmax, LOG2E, -RESCALE_LOG2) > mrun)) {      // wave-uniform; always taken on the first step
+                asm volatile("" ::: "memory");                         // keep it a branch: if-converted it costs 12 VALU ops per step
+                const float mnew = max2_raw(mrun, pmax * LOG2E);       // the first pair holds valid content keys: finite
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                mrun = mnew;
+                if (!ONES) lsum *= alpha;
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) oacc[dd] = oacc[dd] * alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mnew)); sv[hh][j] = p; if (!ONES) psum += p; }
-            if (!ONES) lsum = lsum * alpha + psum;
+                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mrun)); sv[hh][j] = p; if (!ONES) psum += p; }
+            if (!ONES) lsum += psum;
             if (DROP) {                                      // attention dropout acts on P after the softmax sum
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -405,9 +422,12 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
                 const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
                 const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
                                        *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
-                oacc[dd] = mfma16(a, pb, oacc[dd] * alpha);
+                oacc[dd] = mfma16(a, pb, oacc[dd]);
             }
-        }
+        };
+        const int nfull = nt_full / 2;
+        for (int u = 0; u < nfull; ++u) step(u, std::false_type{});
+        for (int u = nfull; u < npairs; ++u) step(u, std::true_type{});
         if (ONES) {                                          // sum_k P sits in O's row hd: lane (r, g = (hd%16)/4), element hd%4
             const int dd1 = hd >> 4, e1 = hd & 3, g1 = (hd & 15) >> 2;
             float pick = 0.f;
@@ -678,8 +698,11 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
-    auto kern = d->attn_drop_thr ? k_win_attn_fwd<DKS, DVT, NW, true, false>
-                                 : (ones ? k_win_attn_fwd<DKS, DVT, NW, false, true> : k_win_attn_fwd<DKS, DVT, NW, false, false>);
+    const bool msk = d->has_mask != 0;
+    auto kern = d->attn_drop_thr
+        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, true, false, true> : k_win_attn_fwd<DKS, DVT, NW, true, false, false>)
+        : ones ? (msk ? k_win_attn_fwd<DKS, DVT, NW, false, true, true> : k_win_attn_fwd<DKS, DVT, NW, false, true, false>)
+               : (msk ? k_win_attn_fwd<DKS, DVT, NW, false, false, true> : k_win_attn_fwd<DKS, DVT, NW, false, false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
