@@ -60,13 +60,22 @@ MIVP_DEV float max3_raw(float a, float b, float c) { return __builtin_elementwis
 //            >= 0: region id; the logit survives only where it equals the query's region id, otherwise
 //                  the reference's multiplicative mask forces it to 0 (window_attention.py:54-56)
 // `live` is false where the logit is a constant (masked or excluded), i.e. where it carries no gradient.
-MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live) {
-    const bool excl = kcls == -1;
-    const bool match = (kcls == -2) | (kcls == rq);
+// Logits live in log2 units: K' (head dims, prompt keys and the bias columns) is stored multiplied by log2(e), so
+// S = K'Q'^T feeds v_exp_f32 directly, and the MFMA accumulator starts at `zero` = -(reference point) (the running max
+// in the forward, the log-sum-exp in the backward): a logit forced to 0 by the mask is therefore the value `zero`.
+template <int PAD, int PROMPT>
+MIVP_DEV float classify_logit_c(float s, int kcls, int rq, bool& live, float zero) {
+    const bool excl = kcls == PAD;
+    const bool match = (kcls == PROMPT) | (kcls == rq);
     live = match & !excl;
-    const float v = match ? s : 0.f;
+    const float v = match ? s : zero;
     return excl ? -INFINITY : v;
 }
+MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live, float zero) {
+    return classify_logit_c<-1, -2>(s, kcls, rq, live, zero);
+}
+constexpr float MIVP_LOG2E = 1.4426950408889634f;
+constexpr float MIVP_LN2 = 0.6931471805599453f;
 
 // Counter-based dropout (no RNG state): one 32-bit hash serves the two elements of an index pair, 16 bits each.
 // Two multiply / xor-shift rounds over (pair index * golden ratio + seed): the counters are consecutive integers, the

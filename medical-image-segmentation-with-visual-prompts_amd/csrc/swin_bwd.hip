@@ -11,7 +11,6 @@
 int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
 
 namespace {
-constexpr float LOG2E = 1.4426950408889634f;
 
 struct TokInfo { long tt, bp, b; int slot, pw; bool live; };
 
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
         const int qt = wave + NW * i;
         const int qrow = qt < nqt ? qt * 16 + r : 0;
         rq[i] = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
-        lse_b[i] = lse[bph * Nqp + qrow] * LOG2E;
+        lse_b[i] = -lse[bph * Nqp + qrow] * MIVP_LOG2E;       // S accumulators start here: exp2(S) is P (common.hpp)
         // delta = sum_j dO * O over this head's channels: each lane covers 4g.. of every 16, then the 4 g-lanes add up
         float acc = 0.f;
         for (int c4 = g; c4 < hd4; c4 += 4) {
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int lt = 2 * u + hh;
-                    f32x4 s = fzero4(), dp = fzero4();
+                    f32x4 s = {lsei, lsei, lsei, lsei}, dp = fzero4();
 #pragma unroll
                     for (int ks = 0; ks < DKS; ++ks)
                         s = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), qf[ks], s);
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                     const bool fast = (t0 + lt) < nt_full && !d.has_mask;
                     if (fast) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) ds[hh][j] = __builtin_amdgcn_exp2f(s[j] * LOG2E - lsei) * (dp[j] - dli);
+                        for (int j = 0; j < 4; ++j) ds[hh][j] = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
                     } else {
                         const int4 kr4 = *reinterpret_cast<const int4*>(ridk + 16 * lt + 4 * g);
                         const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
@@ -387,8 +386,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                         for (int j = 0; j < 4; ++j) {
                             // masked-to-zero logits and padding keys carry no gradient
                             bool live;
-                            const float sv = classify_logit(s[j], krs[j], rqi, live);
-                            const float val = __builtin_amdgcn_exp2f(sv * LOG2E - lsei) * (dp[j] - dli);
+                            const float sv = classify_logit(s[j], krs[j], rqi, live, lsei);
+                            const float val = __builtin_amdgcn_exp2f(sv) * (dp[j] - dli);
                             ds[hh][j] = live ? val : 0.f;
                         }
                     }
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) {
             const int j0 = 16 * dd + 4 * g;
-            if (j0 < hd) st4(dq + ((bph * Nqp + qrow) * (long)hd + j0), pack4(dqacc[i][dd]));
+            if (j0 < hd) st4(dq + ((bph * Nqp + qrow) * (long)hd + j0), pack4(dqacc[i][dd] * MIVP_LN2));   // K carries log2(e)
         }
     }
 }
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
         for (int m = tid; m < nq; m += 64 * NW) {
             const int row = q0 + m;
             const bool ok = row < Nqp;
-            lse_s[m] = ok ? lse[bph * Nqp + row] * LOG2E : 0.f;
+            lse_s[m] = ok ? -lse[bph * Nqp + row] * MIVP_LOG2E : 0.f;    // the S accumulators start from it
             del_s[m] = ok ? delta[bph * Nqp + row] : 0.f;
             ridq[m] = (ok && row < d.Nq) ? (d.has_mask ? tok_rid[pw * Nqp + row] : 0) : -1;   // -1: padding query row
         }
@@ -571,7 +570,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int lt = 2 * u + hh;
-                    f32x4 s = fzero4(), dp = fzero4();
+                    // rows of this accumulator tile are queries 16*lt + 4g + j
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
+                    f32x4 s = {l4.x, l4.y, l4.z, l4.w}, dp = fzero4();
 #pragma unroll
                     for (int ks = 0; ks < DKS; ++ks)
                         s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), kf[ks], s);
@@ -582,8 +583,6 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                         for (int ks = 0; ks < DVS; ++ks)
                             dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
                     }
-                    // rows of this accumulator tile are queries 16*lt + 4g + j
-                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
                     const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
                     const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
                     const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -598,15 +597,15 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                         float p, dsv;
                         if (MASKED) {
                             bool live;
-                            const float sv = classify_logit(s[j], kcls, rqs[j], live);
+                            const float sv = classify_logit(s[j], kcls, rqs[j], live, ls[j]);
                             const bool qok = rqs[j] != -1;                  // padding query rows: no P, no gradient
-                            p = qok ? __builtin_amdgcn_exp2f(sv * LOG2E - ls[j]) : 0.f;
+                            p = qok ? __builtin_amdgcn_exp2f(sv) : 0.f;
                             dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
                         } else {
                             // un-shifted block: every valid key is attended by every valid query -- P = 0 exactly where
                             // either is padding, and dS = P * (...) vanishes with it
                             const bool ok = kvalid & (rqs[j] != -1);
-                            p = ok ? __builtin_amdgcn_exp2f(s[j] * LOG2E - ls[j]) : 0.f;
+                            p = ok ? __builtin_amdgcn_exp2f(s[j]) : 0.f;
                             dsv = p * (dp[j] * keep - dls[j]);
                         }
                         pv[hh][j] = p * keep;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
             const int sel = o_sel, head = o_head, j0 = o_j0;
             o_j0 += 16;
             bf16_t* base = sel == 0 ? q : (sel == 1 ? k : v);
-            const float sc = sel == 0 ? d.q_scale : 1.0f;
+            const float sc = sel == 0 ? d.q_scale : (sel == 1 ? MIVP_LOG2E : 1.0f);    // K carries log2(e): common.hpp
             if (live[0]) st4(base + ((bp[0] * d.heads + head) * d.Nqp + slot[0]) * (long)hd + j0, pack4(acc0 * sc));
             if (live[1]) st4(base + ((bp[1] * d.heads + head) * d.Nqp + slot[1]) * (long)hd + j0, pack4(acc1 * sc));
         }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_prompt_kv_fwd(MivpSwinDesc d, const flo
         float acc = 0.f;
         for (int c = 0; c < C; ++c) acc += y[c] * (float)wrow[c];
         const int head = cc / hd, j = cc - head * hd;
-        (sel == 0 ? kp : vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)acc;
+        (sel == 0 ? kp : vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)(sel == 0 ? acc * MIVP_LOG2E : acc);
     }
 }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
         } else if (m >= d.Nqp && m < d.Nqp + d.Np) {
             if (a < w0) val = ts[(long)head * d.Np + (m - d.Nqp)];
         }
-        ka[((long)head * d.Nkp + m) * A + a] = (bf16_t)val;
+        ka[((long)head * d.Nkp + m) * A + a] = (bf16_t)(val * MIVP_LOG2E);
     }
 }
 
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
 template <int DKS, int DVT, int NW, bool DROP, bool ONES, bool MASKED>
-__global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 8 : 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
     const int VROW = (Nkp + 8) * 2;                          // bytes
     char* Kimg = smem;
     char* Vt = Kimg + (size_t)Nkp * KROW;
-    int* ridk = reinterpret_cast<int*>(Vt + (size_t)(16 * DVT) * VROW);
+    // key classes as bytes (255 padding, 254 prompt, else region id): with 4-byte classes the image is 128 B over a
+    // quarter of the CU's 160 KB at 7^3 windows, i.e. three workgroups per CU instead of four
+    uint8_t* ridk = reinterpret_cast<uint8_t*>(Vt + (size_t)(16 * DVT) * VROW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
     const int A = d.augp;
     const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4;
 
-    // ---- stage K' ----
-    for (int e = tid; e < Nkp * dk4; e += 64 * NW) {
+    // ---- stage K' ----  (loads of four pieces in flight per thread before the first LDS write)
+    auto k_piece = [&](int e) -> bf16x4 {
         const int row = e / dk4, c4 = e - row * dk4;
         bf16x4 val = zero4();
         if (c4 < hd4) {
@@ -296,38 +298,66 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
         } else if (c4 < hd4 + a4) {
             val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
         }
-        *reinterpret_cast<bf16x4*>(Kimg + KR::off(row, 4 * c4)) = val;
-    }
-    // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows) ----
-    for (int e = tid; e < Nkp * (4 * DVT); e += 64 * NW) {
-        const int row = e / (4 * DVT), c4 = e - row * (4 * DVT);
-        bf16x4 val = zero4();
-        if (c4 < hd4) {
-            if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
-            else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
-        }
-        if (ONES && c4 == hd4) val[0] = (bf16_t)1.0f;         // V^T row hd = 1: the PV product then also returns sum_k P
+        return val;
+    };
+    const int k_items = Nkp * dk4;
+    for (int e0 = tid; e0 < k_items; e0 += 4 * 64 * NW) {
+        bf16x4 vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<bf16_t*>(Vt + (size_t)(4 * c4 + i) * VROW + 2 * row) = val[i];
+        for (int i = 0; i < 4; ++i) { const int e = e0 + i * 64 * NW; vals[i] = e < k_items ? k_piece(e) : zero4(); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + i * 64 * NW;
+            if (e < k_items) { const int row = e / dk4, c4 = e - row * dk4; *reinterpret_cast<bf16x4*>(Kimg + KR::off(row, 4 * c4)) = vals[i]; }
+        }
+    }
+    // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows): a thread takes four consecutive keys
+    //      of one 4-channel group, transposes them in registers and writes four 8-byte row pieces ----
+    for (int e = tid; e < (Nkp / 4) * (4 * DVT); e += 64 * NW) {
+        const int rq4 = e / (4 * DVT), c4 = e - rq4 * (4 * DVT);
+        bf16x4 in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * rq4 + i;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
+                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+            }
+            if (ONES && c4 == hd4) val[0] = (bf16_t)1.0f;     // V^T row hd = 1: the PV product then also returns sum_k P
+            in[i] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 outv;
+            outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
+            *reinterpret_cast<bf16x4*>(Vt + (size_t)(4 * c4 + j) * VROW + 2 * (4 * rq4)) = outv;
+        }
     }
     // ---- key classes (classify_logit in common.hpp) ----
     for (int m = tid; m < Nkp; m += 64 * NW) {
         int cls = -1;
         if (m < d.Nq) cls = MASKED ? tok_rid[pw * Nqp + m] : 0;
         else if (m >= Nqp && m < Nqp + d.Np) cls = -2;
-        ridk[m] = cls;
+        ridk[m] = (uint8_t)(cls == -1 ? 255 : (cls == -2 ? 254 : cls));
     }
     __syncthreads();
+    // Most windows of a shifted block are not cut by the volume boundary: all their content tokens share one region id
+    // and the mask is a no-op.  Those windows take the unmasked steps (workgroup-uniform choice).
+    bool cut = false;
+    if (MASKED) {
+        int differs = 0;
+        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= ridk[m] != ridk[0];
+        cut = __syncthreads_or(differs) != 0;
+    }
 
     const int npairs = Nkp / 32;                             // key tiles come in pairs (Nkp % 32 == 0)
     const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
-    const float LOG2E = 1.4426950408889634f;
     constexpr float RESCALE_LOG2 = 8.f;
 
     for (int qt = wave; qt < Nqp / 16; qt += NW) {
         const int qrow = qt * 16 + r;
-        const int rq = (MASKED && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        const uint32_t rq = (MASKED && qrow < d.Nq) ? (uint32_t)tok_rid[pw * Nqp + qrow] : 0u;
         // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
         bf16x8 qf[DKS];
 #pragma unroll
@@ -346,7 +376,9 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
         f32x4 oacc[DVT];
 #pragma unroll
         for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
-        float mrun = -INFINITY, lsum = 0.f;                  // mrun already multiplied by log2(e)
+        float mrun = 0.f, lsum = 0.f;                        // reference point of P, log2 units (set by the first step)
+        f32x4 negm = fzero4();                               // -mrun: the accumulator the S MFMA starts from
+        bool first = true;
         const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
 
         // One step = 32 keys.  TAIL steps hold padding / prompt keys and classify every logit; the others only apply
@@ -355,45 +387,51 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
         // the older reference (P <= 2^RESCALE_LOG2, exact after the final division) -- the exp, the subtract and the
         // O multiplies leave the VALU stream for almost every step.  max3 / max2 are raw v_max instructions: fmaxf()
         // makes the compiler canonicalise each MFMA result first (one extra VALU op per logit).
-        auto step = [&](int u, auto tail_c) {
+        auto step = [&](int u, auto tail_c, auto mask_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
-            f32x4 sv[2];
+            constexpr bool MASK = decltype(mask_c)::value;
+            f32x4 sv[2];                                     // log2-unit logits minus the reference point
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * u + hh;
-                f32x4 acc = fzero4();
+                f32x4 acc = negm;
 #pragma unroll
                 for (int s = 0; s < DKS; ++s)
                     acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * t + r, 32 * s + 8 * g)), qf[s], acc);
                 if (!TAIL || t < nt_full) {
-                    if (MASKED) {
-                        const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
-                        acc[0] = (kr.x == rq) ? acc[0] : 0.f;
-                        acc[1] = (kr.y == rq) ? acc[1] : 0.f;
-                        acc[2] = (kr.z == rq) ? acc[2] : 0.f;
-                        acc[3] = (kr.w == rq) ? acc[3] : 0.f;
+                    if (MASK) {
+                        const uint32_t kr = *reinterpret_cast<const uint32_t*>(ridk + 16 * t + 4 * g);
+                        acc[0] = ((kr & 0xFFu) == rq) ? acc[0] : negm[0];
+                        acc[1] = (((kr >> 8) & 0xFFu) == rq) ? acc[1] : negm[0];
+                        acc[2] = (((kr >> 16) & 0xFFu) == rq) ? acc[2] : negm[0];
+                        acc[3] = ((kr >> 24) == rq) ? acc[3] : negm[0];
                     }
                 } else {
-                    const int4 kr = *reinterpret_cast<const int4*>(ridk + 16 * t + 4 * g);
+                    const uint32_t kr = *reinterpret_cast<const uint32_t*>(ridk + 16 * t + 4 * g);
                     bool live;
-                    acc[0] = classify_logit(acc[0], kr.x, rq, live);
-                    acc[1] = classify_logit(acc[1], kr.y, rq, live);
-                    acc[2] = classify_logit(acc[2], kr.z, rq, live);
-                    acc[3] = classify_logit(acc[3], kr.w, rq, live);
+                    acc[0] = classify_logit_c<255, 254>(acc[0], (int)(kr & 0xFFu), (int)rq, live, negm[0]);
+                    acc[1] = classify_logit_c<255, 254>(acc[1], (int)((kr >> 8) & 0xFFu), (int)rq, live, negm[0]);
+                    acc[2] = classify_logit_c<255, 254>(acc[2], (int)((kr >> 16) & 0xFFu), (int)rq, live, negm[0]);
+                    acc[3] = classify_logit_c<255, 254>(acc[3], (int)(kr >> 24), (int)rq, live, negm[0]);
                 }
-                sv[hh] = acc;                                // natural-log units; log2(e) rides on the fma below
+                sv[hh] = acc;
             }
             float pmax = max3_raw(sv[0][0], sv[0][1], sv[0][2]);
             pmax = max3_raw(pmax, sv[0][3], sv[1][0]);
             pmax = max3_raw(pmax, sv[1][1], sv[1][2]);
-            pmax = max2_raw(pmax, sv[1][3]);
-            pmax = max2_raw(pmax, __shfl_xor(pmax, 16));
-            pmax = max2_raw(pmax, __shfl_xor(pmax, 32));
-            if (__any(fmaf(pmax, LOG2E, -RESCALE_LOG2) > mrun)) {      // wave-uniform; always taken on the first step
+            pmax = max2_raw(pmax, sv[1][3]);                           // this lane's 8 keys only: enough for the test
+            if (first || __any(pmax > RESCALE_LOG2)) {                 // wave-uniform
                 asm volatile("" ::: "memory");                         // keep it a branch: if-converted it costs 12 VALU ops per step
-                const float mnew = max2_raw(mrun, pmax * LOG2E);       // the first pair holds valid content keys: finite
-                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                mrun = mnew;
+                pmax = max2_raw(pmax, __shfl_xor(pmax, 16));           // the query's four lanes must agree on the new point
+                pmax = max2_raw(pmax, __shfl_xor(pmax, 32));
+                // the first pair holds valid content keys (finite max) and always sets the reference point
+                const float up = first ? pmax : max2_raw(pmax, 0.f);
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
+                first = false;
+                mrun += up;
+                negm = negm - up;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) sv[hh] = sv[hh] - up;
                 if (!ONES) lsum *= alpha;
 #pragma unroll
                 for (int dd = 0; dd < DVT; ++dd) oacc[dd] = oacc[dd] * alpha;
@@ -402,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(fmaf(sv[hh][j], LOG2E, -mrun)); sv[hh][j] = p; if (!ONES) psum += p; }
+                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(sv[hh][j]); sv[hh][j] = p; if (!ONES) psum += p; }
             if (!ONES) lsum += psum;
             if (DROP) {                                      // attention dropout acts on P after the softmax sum
 #pragma unroll
@@ -426,8 +464,13 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
             }
         };
         const int nfull = nt_full / 2;
-        for (int u = 0; u < nfull; ++u) step(u, std::false_type{});
-        for (int u = nfull; u < npairs; ++u) step(u, std::true_type{});
+        if (MASKED && cut) {
+            for (int u = 0; u < nfull; ++u) step(u, std::false_type{}, std::true_type{});
+            for (int u = nfull; u < npairs; ++u) step(u, std::true_type{}, std::true_type{});
+        } else {
+            for (int u = 0; u < nfull; ++u) step(u, std::false_type{}, std::false_type{});
+            for (int u = nfull; u < npairs; ++u) step(u, std::true_type{}, std::false_type{});
+        }
         if (ONES) {                                          // sum_k P sits in O's row hd: lane (r, g = (hd%16)/4), element hd%4
             const int dd1 = hd >> 4, e1 = hd & 3, g1 = (hd & 15) >> 2;
             float pick = 0.f;
@@ -445,7 +488,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_fwd(MivpSwinDesc d, const 
             const int j0 = 16 * dd + 4 * g;
             if (j0 < hd) st4(o + ((bp * Nqp + qrow) * (long)C + head * hd + j0), pack4(oacc[dd] * inv));
         }
-        if (g == 0) lse[bph * Nqp + qrow] = (mrun + __builtin_amdgcn_logf(lsum)) * 0.6931471805599453f;
+        if (g == 0) lse[bph * Nqp + qrow] = (mrun + __builtin_amdgcn_logf(lsum)) * MIVP_LN2;
     }
 }
 
@@ -695,7 +738,7 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
                            hipStream_t st) {
     constexpr int NW = 8;
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
-    const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp * 4;
+    const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
     const bool msk = d->has_mask != 0;
