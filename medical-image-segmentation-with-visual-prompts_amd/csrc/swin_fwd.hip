@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   keeps the kernel under 128 VGPRs so that 16+ waves per CU hide the LDS / MFMA / exp latency
 //   (this kernel is bound by VALU + transcendental issue, not by MFMA: DESIGN.md section 4).
 // ---------------------------------------------------------------------------------------------
-template <int DKS, int DVT, int NW, bool DROP, bool ONES, bool MASKED>
-__global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 8 : 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED>
+__global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
@@ -288,50 +288,65 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 8 : 2) void k_win_at
     const int A = d.augp;
     const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4;
 
+    // Staging is VALU work in a VALU-bound kernel (it used to be more than a third of the kernel's vector instructions):
+    // per-workgroup bases are uniform, a thread keeps ONE column of the image so its source, stride and LDS column are
+    // loop invariants, and offsets are 32-bit.
+    const bf16_t* kb = k + bph * (long)Nqp * hd;             // this (window, head)'s rows
+    const bf16_t* vb = v + bph * (long)Nqp * hd;
+    const bf16_t* kpb = d.Np > 0 ? kp + (long)head * d.Npp * hd : kb;
+    const bf16_t* vpb = d.Np > 0 ? vp + (long)head * d.Npp * hd : vb;
+    const bf16_t* kab = ka + (long)head * Nkp * A;
+    const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
     // ---- stage K' ----  (loads of four pieces in flight per thread before the first LDS write)
-    auto k_piece = [&](int e) -> bf16x4 {
-        const int row = e / dk4, c4 = e - row * dk4;
-        bf16x4 val = zero4();
-        if (c4 < hd4) {
-            if (row < Nqp) val = ld4(k + ((bph * Nqp + row) * (long)hd + 4 * c4));
-            else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
-        } else if (c4 < hd4 + a4) {
-            val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
-        }
-        return val;
-    };
-    const int k_items = Nkp * dk4;
-    for (int e0 = tid; e0 < k_items; e0 += 4 * 64 * NW) {
-        bf16x4 vals[4];
+    {
+        constexpr int RPP = 64 * NW / dk4;                   // rows per pass
+        const int c4 = tid % dk4, row0 = tid / dk4;
+        const bool from_k = c4 < hd4, from_a = !from_k && c4 < hd4 + a4;
+        const bf16_t* src = from_k ? kb : kab;
+        const uint32_t stride = from_k ? hd : A, coff = from_k ? 4 * c4 : 4 * (c4 - hd4);
+        const int rows_main = from_k ? Nqp : (from_a ? Nkp : 0);
+        for (int rowb = row0; rowb < Nkp; rowb += 4 * RPP) {
+            bf16x4 vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int e = e0 + i * 64 * NW; vals[i] = e < k_items ? k_piece(e) : zero4(); }
+            for (int i = 0; i < 4; ++i) {
+                const int row = rowb + i * RPP;
+                bf16x4 val = zero4();
+                if (row < rows_main) val = ld4(src + ((uint32_t)row * stride + coff));
+                else if (from_k && row < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(row - Nqp) * hd + coff));
+                vals[i] = val;
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = e0 + i * 64 * NW;
-            if (e < k_items) { const int row = e / dk4, c4 = e - row * dk4; *reinterpret_cast<bf16x4*>(Kimg + KR::off(row, 4 * c4)) = vals[i]; }
+            for (int i = 0; i < 4; ++i) {
+                const int row = rowb + i * RPP;
+                if (row < Nkp) *reinterpret_cast<bf16x4*>(Kimg + KR::off(row, 4 * c4)) = vals[i];
+            }
         }
     }
     // ---- stage V^T (zero rows dv >= hd, zero key columns beyond the staged rows): a thread takes four consecutive keys
     //      of one 4-channel group, transposes them in registers and writes four 8-byte row pieces ----
-    for (int e = tid; e < (Nkp / 4) * (4 * DVT); e += 64 * NW) {
-        const int rq4 = e / (4 * DVT), c4 = e - rq4 * (4 * DVT);
-        bf16x4 in[4];
+    {
+        constexpr int CPR = 4 * DVT, RPP = 64 * NW / CPR;
+        const int c4 = tid % CPR;
+        const bool from_v = c4 < hd4;
+        for (int rq4 = tid / CPR; rq4 < Nkp / 4; rq4 += RPP) {
+            bf16x4 in[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * rq4 + i;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
-                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rq4 + i;
+                bf16x4 val = zero4();
+                if (from_v) {
+                    if (row < Nqp) val = ld4(vb + ((uint32_t)row * hd + 4 * c4));
+                    else if (row < Nqp + n_prompt_rows) val = ld4(vpb + ((uint32_t)(row - Nqp) * hd + 4 * c4));
+                }
+                if (ONES && c4 == hd4) val[0] = (bf16_t)1.0f; // V^T row hd = 1: the PV product then also returns sum_k P
+                in[i] = val;
             }
-            if (ONES && c4 == hd4) val[0] = (bf16_t)1.0f;     // V^T row hd = 1: the PV product then also returns sum_k P
-            in[i] = val;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bf16x4 outv;
-            outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
-            *reinterpret_cast<bf16x4*>(Vt + (size_t)(4 * c4 + j) * VROW + 2 * (4 * rq4)) = outv;
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 outv;
+                outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
+                *reinterpret_cast<bf16x4*>(Vt + (size_t)(4 * c4 + j) * VROW + 2 * (4 * rq4)) = outv;
+            }
         }
     }
     // ---- key classes (classify_logit in common.hpp) ----
@@ -355,112 +370,157 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 8 : 2) void k_win_at
     const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
     constexpr float RESCALE_LOG2 = 8.f;
 
-    for (int qt = wave; qt < Nqp / 16; qt += NW) {
-        const int qrow = qt * 16 + r;
-        const uint32_t rq = (MASKED && qrow < d.Nq) ? (uint32_t)tok_rid[pw * Nqp + qrow] : 0u;
-        // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
-        bf16x8 qf[DKS];
+    // A wave carries QT query tiles through the key loop at once: every K' / V^T fragment read from LDS serves QT tiles
+    // (the LDS pipe is the co-bottleneck of this kernel) and the QT softmax chains are independent instruction streams.
+    const int nqt = Nqp / 16;
+    const bf16_t* qb = q + bph * (long)Nqp * hd;
+    bf16_t* ob = o + bp * (long)Nqp * C + head * hd;
+    for (int qt0 = QT * wave; qt0 < nqt; qt0 += QT * NW) {
+        int qrow[QT];
+        uint32_t rq[QT];
+        bf16x8 qf[QT][DKS];
+        f32x4 oacc[QT][DVT], negm[QT];                       // negm = -(reference point): the accumulator the S MFMA starts from
+        float mrun[QT], lsum[QT];                            // reference point of P in log2 units (set by the first step)
+        uint32_t drow[QT];
 #pragma unroll
-        for (int s = 0; s < DKS; ++s) {
-            bf16x4 piece[2];
+        for (int a = 0; a < QT; ++a) {
+            const int qt = (qt0 + a < nqt) ? qt0 + a : qt0;  // an odd tile count: the spare slot shadows tile qt0, nothing stored
+            qrow[a] = qt * 16 + r;
+            rq[a] = (MASKED && qrow[a] < d.Nq) ? (uint32_t)tok_rid[pw * Nqp + qrow[a]] : 0u;
+            // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
 #pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                const int c4 = 8 * s + 2 * g + hlf;
-                bf16x4 val = zero4();
-                if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
-                else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
-                piece[hlf] = val;
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf;
+                    bf16x4 val = zero4();
+                    if (c4 < hd4) val = ld4(qb + ((uint32_t)qrow[a] * hd + 4 * c4));
+                    else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)qrow[a] * A + 4 * (c4 - hd4)));
+                    piece[hlf] = val;
+                }
+                qf[a][s] = cat44(piece[0], piece[1]);
             }
-            qf[s] = cat44(piece[0], piece[1]);
-        }
-        f32x4 oacc[DVT];
 #pragma unroll
-        for (int dd = 0; dd < DVT; ++dd) oacc[dd] = fzero4();
-        float mrun = 0.f, lsum = 0.f;                        // reference point of P, log2 units (set by the first step)
-        f32x4 negm = fzero4();                               // -mrun: the accumulator the S MFMA starts from
+            for (int dd = 0; dd < DVT; ++dd) oacc[a][dd] = fzero4();
+            negm[a] = fzero4();
+            mrun[a] = 0.f;
+            lsum[a] = 0.f;
+            drow[a] = DROP ? attn_row(bph, qrow[a], Nqp, Nkp) : 0u;
+        }
         bool first = true;
-        const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
 
         // One step = 32 keys.  TAIL steps hold padding / prompt keys and classify every logit; the others only apply
-        // the shift mask (MASKED).  The running max is refreshed lazily: only when some query of the wave sees a logit
-        // more than RESCALE_LOG2 above its reference point are O (and the sum) rescaled, otherwise P is formed against
-        // the older reference (P <= 2^RESCALE_LOG2, exact after the final division) -- the exp, the subtract and the
-        // O multiplies leave the VALU stream for almost every step.  max3 / max2 are raw v_max instructions: fmaxf()
-        // makes the compiler canonicalise each MFMA result first (one extra VALU op per logit).
+        // the shift mask (MASK).  Logits arrive in log2 units relative to the reference point (common.hpp).  The
+        // reference is refreshed lazily: only when some lane of the wave sees a logit more than RESCALE_LOG2 above it
+        // are O (and the sum) rescaled, otherwise P is formed against the older reference (P <= 2^RESCALE_LOG2, exact
+        // after the final division) -- the cross-lane max, the exp, the subtract and the O multiplies leave the VALU /
+        // LDS streams for almost every step.  max3 / max2 are v_maximum3_f32: fmaxf() makes the compiler canonicalise
+        // each MFMA result first (one extra VALU op per logit).
         auto step = [&](int u, auto tail_c, auto mask_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
             constexpr bool MASK = decltype(mask_c)::value;
-            f32x4 sv[2];                                     // log2-unit logits minus the reference point
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int t = 2 * u + hh;
-                f32x4 acc = negm;
-#pragma unroll
-                for (int s = 0; s < DKS; ++s)
-                    acc = mfma16(*reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * t + r, 32 * s + 8 * g)), qf[s], acc);
-                if (!TAIL || t < nt_full) {
-                    if (MASK) {
-                        const uint32_t kr = *reinterpret_cast<const uint32_t*>(ridk + 16 * t + 4 * g);
-                        acc[0] = ((kr & 0xFFu) == rq) ? acc[0] : negm[0];
-                        acc[1] = (((kr >> 8) & 0xFFu) == rq) ? acc[1] : negm[0];
-                        acc[2] = (((kr >> 16) & 0xFFu) == rq) ? acc[2] : negm[0];
-                        acc[3] = ((kr >> 24) == rq) ? acc[3] : negm[0];
-                    }
-                } else {
-                    const uint32_t kr = *reinterpret_cast<const uint32_t*>(ridk + 16 * t + 4 * g);
-                    bool live;
-                    acc[0] = classify_logit_c<255, 254>(acc[0], (int)(kr & 0xFFu), (int)rq, live, negm[0]);
-                    acc[1] = classify_logit_c<255, 254>(acc[1], (int)((kr >> 8) & 0xFFu), (int)rq, live, negm[0]);
-                    acc[2] = classify_logit_c<255, 254>(acc[2], (int)((kr >> 16) & 0xFFu), (int)rq, live, negm[0]);
-                    acc[3] = classify_logit_c<255, 254>(acc[3], (int)(kr >> 24), (int)rq, live, negm[0]);
-                }
-                sv[hh] = acc;
-            }
-            float pmax = max3_raw(sv[0][0], sv[0][1], sv[0][2]);
-            pmax = max3_raw(pmax, sv[0][3], sv[1][0]);
-            pmax = max3_raw(pmax, sv[1][1], sv[1][2]);
-            pmax = max2_raw(pmax, sv[1][3]);                           // this lane's 8 keys only: enough for the test
-            if (first || __any(pmax > RESCALE_LOG2)) {                 // wave-uniform
-                asm volatile("" ::: "memory");                         // keep it a branch: if-converted it costs 12 VALU ops per step
-                pmax = max2_raw(pmax, __shfl_xor(pmax, 16));           // the query's four lanes must agree on the new point
-                pmax = max2_raw(pmax, __shfl_xor(pmax, 32));
-                // the first pair holds valid content keys (finite max) and always sets the reference point
-                const float up = first ? pmax : max2_raw(pmax, 0.f);
-                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
-                first = false;
-                mrun += up;
-                negm = negm - up;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) sv[hh] = sv[hh] - up;
-                if (!ONES) lsum *= alpha;
-#pragma unroll
-                for (int dd = 0; dd < DVT; ++dd) oacc[dd] = oacc[dd] * alpha;
-            }
-            float psum = 0.f;
+            bf16x8 kfr[2][DKS];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float p = __builtin_amdgcn_exp2f(sv[hh][j]); sv[hh][j] = p; if (!ONES) psum += p; }
-            if (!ONES) lsum += psum;
-            if (DROP) {                                      // attention dropout acts on P after the softmax sum
+                for (int s = 0; s < DKS; ++s)
+                    kfr[hh][s] = *reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * (2 * u + hh) + r, 32 * s + 8 * g));
+            uint32_t kcl[2] = {0u, 0u};
+            if (MASK || TAIL) {
+                kcl[0] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u) + 4 * g);
+                kcl[1] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u + 1) + 4 * g);
+            }
+            f32x4 sv[QT][2];                                 // log2-unit logits minus the reference point
+            float pmax[QT];
+            bool grow = first;
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int key0 = 16 * (2 * u + hh) + 4 * g;
-                    const uint32_t pi = attn_pair(drow, key0);
-                    const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
-                    sv[hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[hh][0] : 0.f;
-                    sv[hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[hh][1] : 0.f;
-                    sv[hh][2] = drop_keep(h1, 0, d.attn_drop_thr) ? sv[hh][2] : 0.f;
-                    sv[hh][3] = drop_keep(h1, 1, d.attn_drop_thr) ? sv[hh][3] : 0.f;
+                    const int t = 2 * u + hh;
+                    f32x4 acc = negm[a];
+#pragma unroll
+                    for (int s = 0; s < DKS; ++s) acc = mfma16(kfr[hh][s], qf[a][s], acc);
+                    const uint32_t kr = kcl[hh];
+                    if (!TAIL || t < nt_full) {
+                        if (MASK) {
+                            acc[0] = ((kr & 0xFFu) == rq[a]) ? acc[0] : negm[a][0];
+                            acc[1] = (((kr >> 8) & 0xFFu) == rq[a]) ? acc[1] : negm[a][0];
+                            acc[2] = (((kr >> 16) & 0xFFu) == rq[a]) ? acc[2] : negm[a][0];
+                            acc[3] = ((kr >> 24) == rq[a]) ? acc[3] : negm[a][0];
+                        }
+                    } else if (!MASK) {
+                        // no shift mask: content and prompt keys are all attended, only padding keys are excluded
+                        acc[0] = ((kr & 0xFFu) == 255u) ? -INFINITY : acc[0];
+                        acc[1] = (((kr >> 8) & 0xFFu) == 255u) ? -INFINITY : acc[1];
+                        acc[2] = (((kr >> 16) & 0xFFu) == 255u) ? -INFINITY : acc[2];
+                        acc[3] = ((kr >> 24) == 255u) ? -INFINITY : acc[3];
+                    } else {
+                        bool live;
+                        acc[0] = classify_logit_c<255, 254>(acc[0], (int)(kr & 0xFFu), (int)rq[a], live, negm[a][0]);
+                        acc[1] = classify_logit_c<255, 254>(acc[1], (int)((kr >> 8) & 0xFFu), (int)rq[a], live, negm[a][0]);
+                        acc[2] = classify_logit_c<255, 254>(acc[2], (int)((kr >> 16) & 0xFFu), (int)rq[a], live, negm[a][0]);
+                        acc[3] = classify_logit_c<255, 254>(acc[3], (int)(kr >> 24), (int)rq[a], live, negm[a][0]);
+                    }
+                    sv[a][hh] = acc;
                 }
+                float pm = max3_raw(sv[a][0][0], sv[a][0][1], sv[a][0][2]);
+                pm = max3_raw(pm, sv[a][0][3], sv[a][1][0]);
+                pm = max3_raw(pm, sv[a][1][1], sv[a][1][2]);
+                pmax[a] = max2_raw(pm, sv[a][1][3]);         // this lane's 8 keys only: enough for the test
+                grow = grow || (pmax[a] > RESCALE_LOG2);
             }
-            const bf16x8 pb = cat44(pack4(sv[0]), pack4(sv[1]));
+            if (first || __any(grow)) {                      // wave-uniform
+                asm volatile("" ::: "memory");               // keep it a branch: if-converted it costs 12 VALU ops per step
+#pragma unroll
+                for (int a = 0; a < QT; ++a) {
+                    float pm = pmax[a];
+                    pm = max2_raw(pm, __shfl_xor(pm, 16));   // the query's four lanes must agree on the new point
+                    pm = max2_raw(pm, __shfl_xor(pm, 32));
+                    // the first pair holds valid content keys (finite max) and always sets the reference point
+                    const float up = first ? pm : max2_raw(pm, 0.f);
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
+                    mrun[a] += up;
+                    negm[a] = negm[a] - up;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) sv[a][hh] = sv[a][hh] - up;
+                    if (!ONES) lsum[a] *= alpha;
+#pragma unroll
+                    for (int dd = 0; dd < DVT; ++dd) oacc[a][dd] = oacc[a][dd] * alpha;
+                }
+                first = false;
+            }
+            bf16x8 vfr[DVT];
 #pragma unroll
             for (int dd = 0; dd < DVT; ++dd) {
                 const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
-                const bf16x8 a = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
-                                       *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
-                oacc[dd] = mfma16(a, pb, oacc[dd]);
+                vfr[dd] = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
+                                *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
+            }
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                float psum = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float pe = __builtin_amdgcn_exp2f(sv[a][hh][j]); sv[a][hh][j] = pe; if (!ONES) psum += pe; }
+                if (!ONES) lsum[a] += psum;
+                if (DROP) {                                  // attention dropout acts on P after the softmax sum
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int key0 = 16 * (2 * u + hh) + 4 * g;
+                        const uint32_t pi = attn_pair(drow[a], key0);
+                        const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
+                        sv[a][hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[a][hh][0] : 0.f;
+                        sv[a][hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[a][hh][1] : 0.f;
+                        sv[a][hh][2] = drop_keep(h1, 0, d.attn_drop_thr) ? sv[a][hh][2] : 0.f;
+                        sv[a][hh][3] = drop_keep(h1, 1, d.attn_drop_thr) ? sv[a][hh][3] : 0.f;
+                    }
+                }
+                const bf16x8 pb = cat44(pack4(sv[a][0]), pack4(sv[a][1]));
+#pragma unroll
+                for (int dd = 0; dd < DVT; ++dd) oacc[a][dd] = mfma16(vfr[dd], pb, oacc[a][dd]);
             }
         };
         const int nfull = nt_full / 2;
@@ -471,24 +531,29 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 8 : 2) void k_win_at
             for (int u = 0; u < nfull; ++u) step(u, std::false_type{}, std::false_type{});
             for (int u = nfull; u < npairs; ++u) step(u, std::true_type{}, std::false_type{});
         }
-        if (ONES) {                                          // sum_k P sits in O's row hd: lane (r, g = (hd%16)/4), element hd%4
-            const int dd1 = hd >> 4, e1 = hd & 3, g1 = (hd & 15) >> 2;
-            float pick = 0.f;
 #pragma unroll
-            for (int dd = 0; dd < DVT; ++dd)
+        for (int a = 0; a < QT; ++a) {
+            if (a > 0 && qt0 + a >= nqt) continue;
+            float ls = lsum[a];
+            if (ONES) {                                      // sum_k P sits in O's row hd: lane (r, g = (hd%16)/4), element hd%4
+                const int dd1 = hd >> 4, e1 = hd & 3, g1 = (hd & 15) >> 2;
+                float pick = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pick = (dd == dd1 && e == e1) ? oacc[dd][e] : pick;
-            lsum = __shfl(pick, r + 16 * g1);
-        } else {
-            lsum = col_sum(lsum);
+                for (int dd = 0; dd < DVT; ++dd)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pick = (dd == dd1 && e == e1) ? oacc[a][dd][e] : pick;
+                ls = __shfl(pick, r + 16 * g1);
+            } else {
+                ls = col_sum(ls);
+            }
+            const float inv = (DROP ? d.attn_drop_scale : 1.0f) * __builtin_amdgcn_rcpf(ls);
+#pragma unroll
+            for (int dd = 0; dd < DVT; ++dd) {
+                const int j0 = 16 * dd + 4 * g;
+                if (j0 < hd) st4(ob + ((uint32_t)qrow[a] * C + j0), pack4(oacc[a][dd] * inv));
+            }
+            if (g == 0) lse[bph * Nqp + qrow[a]] = (mrun[a] + __builtin_amdgcn_logf(ls)) * MIVP_LN2;
         }
-        const float inv = (DROP ? d.attn_drop_scale : 1.0f) / lsum;
-#pragma unroll
-        for (int dd = 0; dd < DVT; ++dd) {
-            const int j0 = 16 * dd + 4 * g;
-            if (j0 < hd) st4(o + ((bp * Nqp + qrow) * (long)C + head * hd + j0), pack4(oacc[dd] * inv));
-        }
-        if (g == 0) lse[bph * Nqp + qrow] = (mrun + __builtin_amdgcn_logf(lsum)) * MIVP_LN2;
     }
 }
 
@@ -732,20 +797,19 @@ extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const f
     return mivp_check_launch("relbias_aug");
 }
 
-template <int DKS, int DVT>
-static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
-                           const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
-                           hipStream_t st) {
-    constexpr int NW = 8;
+template <int DKS, int DVT, int NW, int QT>
+static int launch_attn_fwd_cfg(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                               const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
+                               hipStream_t st) {
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
     const bool msk = d->has_mask != 0;
     auto kern = d->attn_drop_thr
-        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, true, false, true> : k_win_attn_fwd<DKS, DVT, NW, true, false, false>)
-        : ones ? (msk ? k_win_attn_fwd<DKS, DVT, NW, false, true, true> : k_win_attn_fwd<DKS, DVT, NW, false, true, false>)
-               : (msk ? k_win_attn_fwd<DKS, DVT, NW, false, false, true> : k_win_attn_fwd<DKS, DVT, NW, false, false, false>);
+        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, true, false, true> : k_win_attn_fwd<DKS, DVT, NW, QT, true, false, false>)
+        : ones ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false>)
+               : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
@@ -754,6 +818,15 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse);
     return mivp_check_launch("win_attn_fwd");
+}
+
+template <int DKS, int DVT>
+static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                           const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
+                           hipStream_t st) {
+    // (NW, QT) = (4, 2) -- two query tiles per wave sharing every K' / V^T fragment -- measures the same as (8, 1) at 7^3
+    // windows (87.5 vs 87.2 us per stage-1 block): the kernel is bound by VALU issue, not by the LDS pipe
+    return launch_attn_fwd_cfg<DKS, DVT, 8, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
 }
 
 // shared by forward and backward dispatch: which (NT, DKS=DVT) instantiation covers this shape

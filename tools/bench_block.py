@@ -2,7 +2,8 @@
 usage: python tools/bench_block.py [stage] [iters]   stage in {enc0, enc1, enc2, dec0, dec1, dec2}"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mivp_amd
 from mivp_amd import swin_ops
 from oracle.unetr_ref import _block_state
