@@ -25,30 +25,40 @@
 
 namespace {
 
-// output brick 4 x BW x 16 voxels, BW = 8 (8 waves, 512 voxels) or 4 (4 waves, 256 voxels: the mid-size decoder stages,
-// whose 12- and 24-voxel axes an 8-wide brick would mostly pad); every wave owns 4 tiles of 16 voxels along d
-constexpr int HB_H = 4, HB_D = 16;
-constexpr int HH = HB_H + 2, HD = HB_D + 2;
+// output brick BH x BW x 16 voxels; a wave owns TPW tiles of 16 voxels along d (consecutive along w):
+//   4 x 8 x 16, 8 waves x 4 tiles   (512 voxels)
+//   4 x 4 x 16, 4 waves x 4 tiles   (256 voxels: the mid-size decoder stages, whose 12- and 24-voxel axes an 8-wide
+//                                    brick would mostly pad)
+//   6 x 6 x 16, 12 waves x 3 tiles  (576 voxels: 48^3 x 4 volumes are 768 such bricks = exactly three per CU, where the
+//                                    864 4x8x16 bricks need a fourth, 3/8-full round)
+constexpr int HB_D = 16, HD = HB_D + 2;
 constexpr int KSTEPS = 14;                                    // 28 taps (27 + one zero tap) x 16 channels / 32
-template <int BW>
+template <int BH, int BW, int TPW>
 struct HaloGeom {
-    static constexpr int HW = BW + 2;
-    static constexpr int HROWS = HH * HW * HD;                 // 1080 (BW 8) / 648 (BW 4)
+    static constexpr int HH = BH + 2, HW = BW + 2;
+    static constexpr int HROWS = HH * HW * HD;                 // 1080 (4x8) / 648 (4x4) / 1152 (6x6)
     static constexpr int HALO_BYTES = HROWS * 32;
-    static constexpr int THREADS = 64 * BW;
+    static constexpr int WAVES = BH * BW / TPW, TILES = TPW;
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int HPIECES = (HROWS * 2 + THREADS - 1) / THREADS;   // 16-byte halo pieces per thread
+    static_assert(BW % TPW == 0, "a wave's tiles stay in one brick row");
 };
+template <int BRICK> struct BrickOf;
+template <> struct BrickOf<8> { using G = HaloGeom<4, 8, 4>; };
+template <> struct BrickOf<4> { using G = HaloGeom<4, 4, 4>; };
+template <> struct BrickOf<6> { using G = HaloGeom<6, 6, 3>; };
 
 MIVP_DEV int halo_off(int row, int half) { return row * 32 + (half << 4); }
 MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
-template <int NTN, int HB_W>
-__global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
+template <int NTN, int BRICK>
+__global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ wh, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const bf16_t* __restrict__ residual, bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using GEO = HaloGeom<HB_W>;
+    using GEO = typename BrickOf<BRICK>::G;
+    constexpr int HB_H = GEO::HH - 2, HB_W = GEO::HW - 2, TPW = GEO::TILES;
     constexpr int HW = GEO::HW, HROWS = GEO::HROWS, HALO_BYTES = GEO::HALO_BYTES, HTHREADS = GEO::THREADS, HPIECES = GEO::HPIECES;
     constexpr int BN = 16 * NTN;
     constexpr int WBYTES = KSTEPS * BN * 64;
@@ -103,14 +113,16 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
     bf16x8 hreg[HPIECES], wreg[WPIECES];
     int fetched_chunk = 0;
     auto fetch = [&](int c) {
+        // every load is unconditional (pieces outside the volume read a clamped, valid address and are zeroed when they are
+        // written to LDS): a select on the loaded value here would make the wave wait for its own loads in every chunk
 #pragma unroll
-        for (int u = 0; u < HPIECES; ++u) hreg[u] = hsrc[u] >= 0 ? ld8(x + hsrc[u] + 16 * c) : zero8();
+        for (int u = 0; u < HPIECES; ++u) hreg[u] = ld8(x + (hsrc[u] >= 0 ? hsrc[u] : 0) + 16 * c);
         fetched_chunk = c;
         const bf16_t* wsrc = wh + (long)c * (WBYTES / 2);
 #pragma unroll
         for (int u = 0; u < WPIECES; ++u) {
             const int p = tid + HTHREADS * u;
-            wreg[u] = p < WBYTES / 16 ? ld8(wsrc + 8 * p) : zero8();
+            wreg[u] = ld8(wsrc + 8 * (p < WBYTES / 16 ? p : 0));
         }
     };
     auto stage = [&](int buf) {
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
 #pragma unroll
         for (int u = 0; u < HPIECES; ++u) {
             if (hdst[u] < 0) continue;
-            bf16x8 v = hreg[u];
+            bf16x8 v = hsrc[u] >= 0 ? hreg[u] : zero8();
             if (d.pro_affine && hsrc[u] >= 0) {
                 const int c0 = 16 * fetched_chunk + 8 * ((tid + HTHREADS * u) & 1);
 #pragma unroll
@@ -141,18 +153,19 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
         }
     };
 
-    // ---- this wave's four voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
-    const int th = HB_W == 8 ? wave >> 1 : wave, tw0 = HB_W == 8 ? (wave & 1) * 4 : 0;
+    // ---- this wave's TPW voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
+    constexpr int WPR = HB_W / TPW;                               // waves per brick row
+    const int th = wave / WPR, tw0 = (wave % WPR) * TPW;
     const int half = g & 1, tsel = g >> 1;
-    int vbyte[4];
+    int vbyte[TPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vbyte[i] = halo_off(((th * HW) + (tw0 + i)) * HD + r, half);
+    for (int i = 0; i < TPW; ++i) vbyte[i] = halo_off(((th * HW) + (tw0 + i)) * HD + r, half);
     // weight fragment: row (16nt + r) of k-step j, chunk g under the row swizzle (constant per lane: j*BN and 16nt are multiples of 16)
     const int wbyte = r * 64 + 16 * wswz(r, g);
 
-    f32x4 acc[4][NTN];
+    f32x4 acc[TPW][NTN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TPW; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTN; ++nt) acc[i][nt] = fzero4();
 
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
         const char* hs = Hs(buf);
         const char* ws = Ws(buf) + wbyte;
         // fragments of k-step j+1 are read while the MFMAs of k-step j run (two register sets, loop fully unrolled)
-        bf16x8 vf[2][4], wf[2][NTN];
+        bf16x8 vf[2][TPW], wf[2][NTN];
         auto read_frags = [&](int j, int set) {
             // taps 2j (lanes g < 2) and 2j+1 (g >= 2); tap 27 has zero weights, keep its rows in range
             const int t0 = 2 * j, t1 = 2 * j + 1 < 27 ? 2 * j + 1 : 26;
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
             const int o1 = (((t1 / 9) * HW + (t1 / 3) % 3) * HD + t1 % 3) * 32;
             const int toff = tsel ? o1 : o0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vf[set][i] = *reinterpret_cast<const bf16x8*>(hs + vbyte[i] + toff);
+            for (int i = 0; i < TPW; ++i) vf[set][i] = *reinterpret_cast<const bf16x8*>(hs + vbyte[i] + toff);
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) wf[set][nt] = *reinterpret_cast<const bf16x8*>(ws + (j * BN + 16 * nt) * 64);
         };
@@ -182,33 +195,56 @@ __global__ __launch_bounds__(64 * HB_W) void k_conv3d_halo(MivpConvDesc d, const
         for (int j = 0; j < KSTEPS; ++j) {
             const int cur = j & 1;
             if (j + 1 < KSTEPS) read_frags(j + 1, cur ^ 1);
-            // the next chunk's tiles go to the other LDS buffer late in this chunk: the global loads issued at the top
-            // have landed by then and the writes overlap the remaining MFMAs (that buffer was last read in chunk c-1)
+            // the next chunk's tiles go to the other LDS buffer during this chunk (that buffer was last read in chunk c-1),
+            // late in this chunk: the global loads issued at the top have landed by then and the writes overlap the
+            // remaining MFMAs.  (Spreading the pieces over k-steps 2..12 instead measured 4-20 % SLOWER: the early
+            // writes wait for their loads and an in-order wave stalls its MFMAs behind them.)
             if (j == KSTEPS - 4 && c + 1 < nchunks) stage(buf ^ 1);
+            // Without the fences the machine scheduler sinks every ds_read to just above its first use (read, wait, MFMA):
+            // with two waves per SIMD nothing hides the LDS latency then and the matrix pipe sat at 37 % busy.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][nt] = mfma16(wf[cur][nt], vf[cur][i], acc[i][nt]);
+                for (int i = 0; i < TPW; ++i) acc[i][nt] = mfma16(wf[cur][nt], vf[cur][i], acc[i][nt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: bias, bf16 store (lane: voxel r of tile i, channels 16nt + 4g .. +3)
+    // ---- epilogue: bias, residual, bf16 store (lane: voxel r of tile i, channels 16nt + 4g .. +3).  All bias and residual
+    //      loads are issued before the first use: one exposed memory latency per workgroup instead of one per (tile, nt).
+    f32x4 bv[NTN];
+    bf16x4 rv[TPW][NTN];
+    bool ok[TPW];
+    long voff[TPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int co = co_base + 16 * nt + 4 * g;
+        bv[nt] = (bias && co < d.Cout) ? *reinterpret_cast<const f32x4*>(bias + co) : fzero4();
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
         const int gh = h0 + th, gw = w0 + tw0 + i, gd = d0 + r;
-        if (gh < H && gw < W && gd < D) {
-            const long vox_off = ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
-            bf16_t* yrow = y + vox_off;
+        ok[i] = gh < H && gw < W && gd < D;
+        voff[i] = ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) {
-                const int co = co_base + 16 * nt + 4 * g;
-                if (co < d.Cout) {
-                    f32x4 v = acc[i][nt];
-                    if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
-                    if (residual) { const bf16x4 rv = ld4(residual + vox_off + co); for (int j = 0; j < 4; ++j) v[j] += (float)rv[j]; }
-                    st4(yrow + co, pack4(v));
-                }
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int co = co_base + 16 * nt + 4 * g;
+            rv[i][nt] = (residual && ok[i] && co < d.Cout) ? ld4(residual + voff[i] + co) : zero4();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (!ok[i]) continue;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int co = co_base + 16 * nt + 4 * g;
+            if (co < d.Cout) {
+                f32x4 v = acc[i][nt] + bv[nt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)rv[i][nt][j];
+                st4(y + voff[i] + co, pack4(v));
             }
         }
     }
@@ -237,13 +273,14 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     MIVP_REQUIRE(d && x && wh && y);
     MIVP_REQUIRE(!d->pro_affine || (scale && shift));
     MIVP_REQUIRE((d->add_residual != 0) == (residual != nullptr));
-    MIVP_REQUIRE(brick_w == 4 || brick_w == 8);
+    MIVP_REQUIRE(brick_w == 4 || brick_w == 8 || brick_w == 6);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
     const int groups = (d->Cout + 47) / 48;
     const int ntn = groups > 1 ? 3 : (d->Cout + 15) / 16;
-    const long bricks = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + brick_w - 1) / brick_w) *
+    const int bh = brick_w == 6 ? 6 : 4;
+    const long bricks = (long)d->B * ((d->dims[0] + bh - 1) / bh) * ((d->dims[1] + brick_w - 1) / brick_w) *
                         ((d->dims[2] + HB_D - 1) / HB_D);
-    const size_t halo_bytes = brick_w == 8 ? HaloGeom<8>::HALO_BYTES : HaloGeom<4>::HALO_BYTES;
+    const size_t halo_bytes = brick_w == 8 ? BrickOf<8>::G::HALO_BYTES : (brick_w == 4 ? BrickOf<4>::G::HALO_BYTES : BrickOf<6>::G::HALO_BYTES);
     const size_t lds = 2 * (halo_bytes + (size_t)KSTEPS * 16 * ntn * 64) + (d->pro_affine ? (size_t)2 * d->Cin * sizeof(float) : 0);
     if (lds > 160 * 1024) { mivp_set_error("conv3d_halo_fwd: LDS budget exceeded"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
@@ -251,18 +288,19 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     do {                                                                                                                 \
         auto kern = k_conv3d_halo<N, W>;                                                                                 \
         MIVP_LDS_OPT_IN(kern, lds);                                                                                      \
-        hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(64 * W), lds, st, *d, (const bf16_t*)x,  \
-                           (const bf16_t*)wh, bias, scale, shift, (const bf16_t*)residual, (bf16_t*)y);                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(BrickOf<W>::G::THREADS), lds, st, *d,    \
+                           (const bf16_t*)x, (const bf16_t*)wh, bias, scale, shift, (const bf16_t*)residual, (bf16_t*)y); \
     } while (0)
-    if (brick_w == 8) {
-        if (ntn == 1) HALO_LAUNCH(1, 8);
-        else if (ntn == 2) HALO_LAUNCH(2, 8);
-        else HALO_LAUNCH(3, 8);
-    } else {
-        if (ntn == 1) HALO_LAUNCH(1, 4);
-        else if (ntn == 2) HALO_LAUNCH(2, 4);
-        else HALO_LAUNCH(3, 4);
-    }
+#define HALO_BRICK(W)                                                                                                    \
+    do {                                                                                                                 \
+        if (ntn == 1) HALO_LAUNCH(1, W);                                                                                 \
+        else if (ntn == 2) HALO_LAUNCH(2, W);                                                                            \
+        else HALO_LAUNCH(3, W);                                                                                          \
+    } while (0)
+    if (brick_w == 8) HALO_BRICK(8);
+    else if (brick_w == 4) HALO_BRICK(4);
+    else HALO_BRICK(6);
+#undef HALO_BRICK
 #undef HALO_LAUNCH
     return mivp_check_launch("conv3d_halo_fwd");
 }

@@ -78,20 +78,28 @@ def halo_pack(wp: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
     return wh
 
 
+# halo-brick kernel geometries: code -> (brick h, brick w, voxel tiles per SIMD and k-step)
+_HALO_BRICKS = {8: (4, 8, 8), 4: (4, 4, 4), 6: (6, 6, 9)}
+
+
 def halo_brick(B, dims, cout) -> int:
-    """Brick width (8 or 4) for the halo-brick kernel, 0 for the im2col kernel (tiny volumes).  One 128-155 KB workgroup
-    fits a CU and every wave does the same work at either width, so the cost model is rounds = ceil(workgroups / 256);
-    ties go to the narrow brick (more, smaller workgroups fill the chip better).  Measured on the four decoder shapes
-    (tools/bench_conv.py): the halo kernel beats im2col on all of them, 8 wins at 48^3 / 24^3 / 12x12x24, 4 at 6x6x24."""
+    """Brick code (8: 4x8x16, 4: 4x4x16, 6: 6x6x16) for the halo-brick kernel, 0 for the im2col kernel (tiny volumes).
+    One 128-160 KB workgroup fits a CU, so the cost model is rounds = ceil(workgroups / 256) times the work a SIMD does
+    per k-step of one workgroup (+1 for the per-chunk staging / barrier cost); ties go to the smaller brick.  At 48^3 x 4
+    the 6x6x16 brick gives 768 workgroups = exactly three rounds where 4x8x16 needs 864 = a fourth, 3/8-full one;
+    measured on the decoder shapes with tools/bench_conv.py."""
     H, W, D = dims
     if B * H * W * D < 1024:
         return 0
     groups = (cout + 47) // 48
-    rounds = {}
-    for bw in (8, 4):
-        wgs = B * ((H + 3) // 4) * ((W + bw - 1) // bw) * ((D + 15) // 16) * groups
-        rounds[bw] = (wgs + 255) // 256
-    return 8 if rounds[8] < rounds[4] else 4
+    best, best_cost = 0, None
+    for code in (4, 8, 6):
+        bh, bw, tiles = _HALO_BRICKS[code]
+        wgs = B * ((H + bh - 1) // bh) * ((W + bw - 1) // bw) * ((D + 15) // 16) * groups
+        cost = ((wgs + 255) // 256) * (tiles + 1)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = code, cost
+    return best
 
 
 def conv3d_bn_act(x, wp, bias, cout, scale, shift, lrelu, out_f32=False, fuse_prologue=False):

@@ -49,14 +49,16 @@ def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     rd = None if res is None else cl(res)
     y = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=8)
     y4 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=4)      # 4x4x16 bricks, 4 waves
+    y6 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=6)      # 6x6x16 bricks, 12 waves x 3 tiles
     y_ref = ops.conv3d(cl(x), wp, bd, cout, residual=rd)    # tiny volume -> the im2col kernel
     torch.cuda.synchronize()
     assert getattr(wp, "_mivp_halo", None) is not None     # the halo path really ran
-    assert rel_l2(cf(y), want) < 4e-3 and rel_l2(cf(y4), want) < 4e-3
-    assert rel_l2(cf(y), cf(y_ref)) < 2e-3 and rel_l2(cf(y4), cf(y_ref)) < 2e-3
+    assert rel_l2(cf(y), want) < 4e-3 and rel_l2(cf(y4), want) < 4e-3 and rel_l2(cf(y6), want) < 4e-3
+    assert rel_l2(cf(y), cf(y_ref)) < 2e-3 and rel_l2(cf(y4), cf(y_ref)) < 2e-3 and rel_l2(cf(y6), cf(y_ref)) < 2e-3
 
 
-@pytest.mark.parametrize("cin,cout,dims,lrelu,bw", [(144, 48, (9, 13, 21), True, 8), (32, 96, (6, 6, 24), False, 4)])
+@pytest.mark.parametrize("cin,cout,dims,lrelu,bw", [(144, 48, (9, 13, 21), True, 8), (32, 96, (6, 6, 24), False, 4),
+                                                    (144, 48, (13, 9, 21), True, 6)])
 def test_conv3d_halo_fused_prologue(cin, cout, dims, lrelu, bw):
     """BatchNorm affine (+ LeakyReLU) applied while the halo is staged: zero padding stays zero AFTER the activation."""
     from mivp_amd import ops

@@ -2,7 +2,8 @@
 usage: python tools/bench_conv.py [dec2|dec1|dec0|bott|head] [iters]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mivp_amd
 from mivp_amd import ops
 SH = {"headf": (48, 2, (96, 96, 96), True), "dec2": (144, 48, (48, 48, 48), True), "dec1": (288, 96, (24, 24, 24), True), "dec0": (576, 192, (12, 12, 24), True),
