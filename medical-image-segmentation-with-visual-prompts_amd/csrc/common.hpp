@@ -55,8 +55,8 @@ MIVP_DEV float max2_raw(float a, float b) { return __builtin_elementwise_maximum
 MIVP_DEV float max3_raw(float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 
 // Attention logit classes (branch-free: these compile to v_cmp + v_cndmask, never to exec-mask branches).
-//   key class  -1: padding key, excluded from the softmax (logit -> -inf)
-//              -2: prompt key, always attended
+//   key class  -1: excluded from the softmax (logit -> -inf); padding keys no longer use it (MIVP_PAD_KEY_BIAS below)
+//              -2: prompt key or padding key: never masked
 //            >= 0: region id; the logit survives only where it equals the query's region id, otherwise
 //                  the reference's multiplicative mask forces it to 0 (window_attention.py:54-56)
 // `live` is false where the logit is a constant (masked or excluded), i.e. where it carries no gradient.
@@ -75,6 +75,11 @@ MIVP_DEV float classify_logit(float s, int kcls, int rq, bool& live, float zero)
     return classify_logit_c<-1, -2>(s, kcls, rq, live, zero);
 }
 constexpr float MIVP_LOG2E = 1.4426950408889634f;
+// Padding keys (rows Nq..Nqp-1 and the unused prompt rows of K') carry this value in the i0 one-hot columns of the bias
+// augmentation: every valid query then sees the logit -3e4 (x log2 e) there, P underflows to exactly 0 and no kernel
+// spends VALU work on excluding them.  Their key class is the prompt class (always "matches"), so the shift mask --
+// which forces a logit to 0, not to -inf -- never resurrects them.
+constexpr float MIVP_PAD_KEY_BIAS = -30000.0f;
 constexpr float MIVP_LN2 = 0.6931471805599453f;
 
 // Counter-based dropout (no RNG state): one 32-bit hash serves the two elements of an index pair, 16 bits each.

@@ -220,8 +220,8 @@ struct AttnBwdGeom {
     static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
 };
 
-template <int DKS, int DVT, int QPW, int NW, bool DROP>
-__global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
+template <int DKS, int DVT, int QPW, int NW, bool DROP, bool MASKED>
+__global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
         for (int dd = 0; dd < DVT; ++dd) dqacc[i][dd] = fzero4();
         const int qt = wave + NW * i;
         const int qrow = qt < nqt ? qt * 16 + r : 0;
-        rq[i] = (d.has_mask && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
+        rq[i] = (MASKED && qrow < d.Nq) ? tok_rid[pw * Nqp + qrow] : 0;
         lse_b[i] = -lse[bph * Nqp + qrow] * MIVP_LOG2E;       // S accumulators start here: exp2(S) is P (common.hpp)
         // delta = sum_j dO * O over this head's channels: each lane covers 4g.. of every 16, then the 4 g-lanes add up
         float acc = 0.f;
@@ -274,43 +274,67 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 
     const int nt = Nkp / 16;
     const int nt_full = d.Nq / 16;
+    const bf16_t* kb = k + bph * (long)Nqp * hd;             // this (window, head)'s rows; uniform
+    const bf16_t* vb = v + bph * (long)Nqp * hd;
+    const bf16_t* qb = q + bph * (long)Nqp * hd;
+    const bf16_t* kpb = d.Np > 0 ? kp + (long)head * d.Npp * hd : kb;
+    const bf16_t* vpb = d.Np > 0 ? vp + (long)head * d.Npp * hd : vb;
+    const bf16_t* kab = ka + (long)head * Nkp * A;
+    const bf16_t* dob = d_o + bp * (long)Nqp * C + head * hd;
+    const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+    // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op
+    bool cut = false;
+    if (MASKED) {
+        const int first = tok_rid[pw * Nqp];
+        int differs = 0;
+        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= tok_rid[pw * Nqp + m] != first;
+        cut = __syncthreads_or(differs) != 0;
+    }
     for (int t0 = 0; t0 < nt; t0 += chunk_tiles) {
         const int ntc = (nt - t0) < chunk_tiles ? (nt - t0) : chunk_tiles;       // tiles in this chunk (even)
         const int key0 = t0 * 16, nkeys = ntc * 16;
         __syncthreads();
-        for (int e = tid; e < nkeys * dk4; e += 64 * NW) {
-            const int lrow = e / dk4, c4 = e - lrow * dk4, row = key0 + lrow;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (row < Nqp) val = ld4(k + ((bph * Nqp + row) * (long)hd + 4 * c4));
-                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+        {   // K' rows (+ K^T of the head dims): a thread keeps one 8-byte column of the image; 32-bit offsets from uniform bases
+            constexpr int RPP = 64 * NW / dk4;
+            const int c4 = tid % dk4;
+            const bool from_k = c4 < hd4, from_a = !from_k && c4 < hd4 + a4;
+            const bf16_t* src = from_k ? kb : kab;
+            const uint32_t stride = from_k ? hd : A, coff = from_k ? 4 * c4 : 4 * (c4 - hd4);
+            const int rows_main = from_k ? Nqp : (from_a ? Nkp : 0);
+            for (int lrow = tid / dk4; lrow < nkeys; lrow += RPP) {
+                const int row = key0 + lrow;
+                bf16x4 val = zero4();
+                if (row < rows_main) val = ld4(src + ((uint32_t)row * stride + coff));
+                else if (from_k && row < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(row - Nqp) * hd + coff));
+                if (from_k) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
-            } else if (c4 < hd4 + a4) {
-                val = ld4(ka + (((long)head * Nkp + row) * A + 4 * (c4 - hd4)));
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
+                }
+                *reinterpret_cast<bf16x4*>(Kimg + G::KR::off(lrow, 4 * c4)) = val;
             }
-            *reinterpret_cast<bf16x4*>(Kimg + G::KR::off(lrow, 4 * c4)) = val;
         }
         // K^T rows between hd and 16*DVT must be zero (they multiply dS in the dq MFMA)
         for (int e = tid; e < (16 * DVT - hd) * nkeys; e += 64 * NW) {
             const int rr = hd + e / nkeys, col = e % nkeys;
             *reinterpret_cast<bf16_t*>(Kt + (size_t)rr * KTROW + 2 * col) = (bf16_t)0.0f;
         }
-        for (int e = tid; e < nkeys * dvp4; e += 64 * NW) {
-            const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = key0 + lrow;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (row < Nqp) val = ld4(v + ((bph * Nqp + row) * (long)hd + 4 * c4));
-                else if (row < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (row - Nqp)) * hd + 4 * c4));
+        {
+            constexpr int RPP = 64 * NW / dvp4;
+            const int c4 = tid % dvp4;
+            for (int lrow = tid / dvp4; lrow < nkeys; lrow += RPP) {
+                const int row = key0 + lrow;
+                bf16x4 val = zero4();
+                if (c4 < hd4) {
+                    if (row < Nqp) val = ld4(vb + ((uint32_t)row * hd + 4 * c4));
+                    else if (row < Nqp + n_prompt_rows) val = ld4(vpb + ((uint32_t)(row - Nqp) * hd + 4 * c4));
+                }
+                *reinterpret_cast<bf16x4*>(Vimg + (size_t)lrow * VROWB + 8 * c4) = val;
             }
-            *reinterpret_cast<bf16x4*>(Vimg + (size_t)lrow * VROWB + 8 * c4) = val;
         }
         for (int m = tid; m < nkeys; m += 64 * NW) {
             const int row = key0 + m;
-            int cls = -1;
-            if (row < d.Nq) cls = d.has_mask ? tok_rid[pw * Nqp + row] : 0;
-            else if (row >= Nqp && row < Nqp + d.Np) cls = -2;
-            ridk[m] = cls;
+            // content key: region id; prompt and padding keys: -2 = never masked (padding keys are excluded by their bias)
+            ridk[m] = row < d.Nq ? (MASKED ? tok_rid[pw * Nqp + row] : 0) : -2;
         }
         __syncthreads();
 #pragma unroll
@@ -326,8 +350,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                 for (int hlf = 0; hlf < 2; ++hlf) {
                     const int c4 = 8 * s + 2 * g + hlf;
                     bf16x4 val = zero4();
-                    if (c4 < hd4) val = ld4(q + ((bph * Nqp + qrow) * (long)hd + 4 * c4));
-                    else if (c4 < hd4 + a4) val = ld4(qa + ((long)qrow * A + 4 * (c4 - hd4)));
+                    if (c4 < hd4) val = ld4(qb + ((uint32_t)qrow * hd + 4 * c4));
+                    else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)qrow * A + 4 * (c4 - hd4)));
                     piece[hlf] = val;
                 }
                 qf[s] = cat44(piece[0], piece[1]);
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
             bf16x8 dof[DVS];
             bf16x4 dof4 = zero4();
             if (G::V16) {
-                if (g < hd4) dof4 = ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * g));
+                if (g < hd4) dof4 = ld4(dob + ((uint32_t)qrow * C + 4 * g));
             } else {
 #pragma unroll
                 for (int s = 0; s < DVS; ++s) {
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
 #pragma unroll
                     for (int hlf = 0; hlf < 2; ++hlf) {
                         const int c4 = 8 * s + 2 * g + hlf;
-                        piece[hlf] = c4 < hd4 ? ld4(d_o + ((bp * Nqp + qrow) * (long)C + head * hd + 4 * c4)) : zero4();
+                        piece[hlf] = c4 < hd4 ? ld4(dob + ((uint32_t)qrow * C + 4 * c4)) : zero4();
                     }
                     dof[s] = cat44(piece[0], piece[1]);
                 }
@@ -375,8 +399,8 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                         dp[2] = drop_keep(h1, 0, d.attn_drop_thr) ? dp[2] * d.attn_drop_scale : 0.f;
                         dp[3] = drop_keep(h1, 1, d.attn_drop_thr) ? dp[3] * d.attn_drop_scale : 0.f;
                     }
-                    const bool fast = (t0 + lt) < nt_full && !d.has_mask;
-                    if (fast) {
+                    if (!(MASKED && cut)) {
+                        // no shift mask in effect; padding keys are already at P = 0 through their bias (common.hpp)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ds[hh][j] = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
                     } else {
@@ -384,10 +408,9 @@ __global__ __launch_bounds__(64 * NW) void k_win_attn_bwd_dq(MivpSwinDesc d, int
                         const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            // masked-to-zero logits and padding keys carry no gradient
-                            bool live;
-                            const float sv = classify_logit(s[j], krs[j], rqi, live, lsei);
-                            const float val = __builtin_amdgcn_exp2f(sv) * (dp[j] - dli);
+                            // a masked logit is the constant 0: it keeps its share of the softmax but carries no gradient
+                            const bool live = (krs[j] == rqi) | (krs[j] == -2);
+                            const float val = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
                             ds[hh][j] = live ? val : 0.f;
                         }
                     }
@@ -475,6 +498,26 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
     }
 
     const int nqt = (Nqp + 31) / 32 * 2;                      // query tiles rounded to pairs
+    // uniform per-(window, head) bases + 32-bit offsets: 64-bit per-lane addresses cost VALU ops and registers (they spilled)
+    const bf16_t* qb = q + bph * (long)Nqp * hd;
+    const bf16_t* kb = k + bph * (long)Nqp * hd;
+    const bf16_t* vb = v + bph * (long)Nqp * hd;
+    const bf16_t* kpb = d.Np > 0 ? kp + (long)head * d.Npp * hd : kb;
+    const bf16_t* vpb = d.Np > 0 ? vp + (long)head * d.Npp * hd : vb;
+    const bf16_t* kab = ka + (long)head * Nkp * A;
+    const bf16_t* dob = d_o + bp * (long)Nqp * C + head * hd;
+    const float* lseb = lse + bph * (long)Nqp;
+    const float* delb = delta + bph * (long)Nqp;
+    const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+    // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op and the
+    // workgroup takes the un-shifted block's lean path
+    bool cut = false;
+    if (MASKED) {
+        const int first = tok_rid[pw * Nqp];
+        int differs = 0;
+        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= tok_rid[pw * Nqp + m] != first;
+        cut = __syncthreads_or(differs) != 0;
+    }
     for (int t0 = 0; t0 < nqt; t0 += chunk_tiles) {
         const int ntc = (nqt - t0) < chunk_tiles ? (nqt - t0) : chunk_tiles;
         const int q0 = t0 * 16, nq = ntc * 16;
@@ -483,8 +526,8 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
             const int lrow = e / dk4, c4 = e - lrow * dk4, row = q0 + lrow;
             bf16x4 val = zero4();
             if (row < Nqp) {
-                if (c4 < hd4) val = ld4(q + ((bph * Nqp + row) * (long)hd + 4 * c4));
-                else if (c4 < hd4 + a4) val = ld4(qa + ((long)row * A + 4 * (c4 - hd4)));
+                if (c4 < hd4) val = ld4(qb + ((uint32_t)row * hd + 4 * c4));
+                else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)row * A + 4 * (c4 - hd4)));
             }
             if (c4 < 4 * DVT) {
 #pragma unroll
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
         for (int e = tid; e < nq * dvp4; e += 64 * NW) {
             const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
             bf16x4 val = zero4();
-            if (row < Nqp && c4 < hd4) val = ld4(d_o + ((bp * Nqp + row) * (long)C + head * hd + 4 * c4));
+            if (row < Nqp && c4 < hd4) val = ld4(dob + ((uint32_t)row * C + 4 * c4));
             if (c4 < 4 * DVT) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Ot + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = val[i];
@@ -517,135 +560,135 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
         for (int m = tid; m < nq; m += 64 * NW) {
             const int row = q0 + m;
             const bool ok = row < Nqp;
-            lse_s[m] = ok ? -lse[bph * Nqp + row] * MIVP_LOG2E : 0.f;    // the S accumulators start from it
-            del_s[m] = ok ? delta[bph * Nqp + row] : 0.f;
+            lse_s[m] = ok ? -lseb[row] * MIVP_LOG2E : -INFINITY;   // the S accumulators start from it; padding query rows: P = 0
+            del_s[m] = ok ? delb[row] : 0.f;
             ridq[m] = (ok && row < d.Nq) ? (d.has_mask ? tok_rid[pw * Nqp + row] : 0) : -1;   // -1: padding query row
         }
         __syncthreads();
+        auto compute = [&](auto cut_c) {
+            constexpr bool CUT = decltype(cut_c)::value;    // the shift mask is in effect for this window
 #pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int kt = kfirst + kstride * i;
-            if (kt >= nt) continue;
-            const int krow = kt * 16 + r;
-            int kcls = -1;
-            if (krow < d.Nq) kcls = d.has_mask ? tok_rid[pw * Nqp + krow] : 0;
-            else if (krow >= Nqp && krow < Nqp + d.Np) kcls = -2;
-            const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
-            const bool kvalid = kcls != -1;
-            bf16x8 kf[DKS];
+            for (int i = 0; i < KPW; ++i) {
+                const int kt = kfirst + kstride * i;
+                if (kt >= nt) continue;
+                const int krow = kt * 16 + r;
+                // content key: region id; prompt and padding keys: -2 = never masked (padding keys are excluded by their bias)
+                const int kcls = krow < d.Nq ? (d.has_mask ? tok_rid[pw * Nqp + krow] : 0) : -2;
+                const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
+                bf16x8 kf[DKS];
 #pragma unroll
-            for (int s = 0; s < DKS; ++s) {
-                bf16x4 piece[2];
+                for (int s = 0; s < DKS; ++s) {
+                    bf16x4 piece[2];
 #pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int c4 = 8 * s + 2 * g + hlf;
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int c4 = 8 * s + 2 * g + hlf;
+                        bf16x4 val = zero4();
+                        if (c4 < hd4) {
+                            if (krow < Nqp) val = ld4(kb + ((uint32_t)krow * hd + 4 * c4));
+                            else if (krow < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
+                        } else if (c4 < hd4 + a4) {
+                            val = ld4(kab + ((uint32_t)krow * A + 4 * (c4 - hd4)));
+                        }
+                        piece[hlf] = val;
+                    }
+                    kf[s] = cat44(piece[0], piece[1]);
+                }
+                auto vload = [&](int c4) -> bf16x4 {
                     bf16x4 val = zero4();
                     if (c4 < hd4) {
-                        if (krow < Nqp) val = ld4(k + ((bph * Nqp + krow) * (long)hd + 4 * c4));
-                        else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(kp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
-                    } else if (c4 < hd4 + a4) {
-                        val = ld4(ka + (((long)head * Nkp + krow) * A + 4 * (c4 - hd4)));
+                        if (krow < Nqp) val = ld4(vb + ((uint32_t)krow * hd + 4 * c4));
+                        else if (krow < Nqp + n_prompt_rows) val = ld4(vpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
                     }
-                    piece[hlf] = val;
+                    return val;
+                };
+                bf16x8 vf[DVS];
+                bf16x4 vf4 = zero4();
+                if (G::V16) vf4 = vload(g);
+                else {
+#pragma unroll
+                    for (int s = 0; s < DVS; ++s) vf[s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
                 }
-                kf[s] = cat44(piece[0], piece[1]);
-            }
-            auto vload = [&](int c4) -> bf16x4 {
-                bf16x4 val = zero4();
-                if (c4 < hd4) {
-                    if (krow < Nqp) val = ld4(v + ((bph * Nqp + krow) * (long)hd + 4 * c4));
-                    else if (krow < Nqp + d.Npp && d.Np > 0) val = ld4(vp + (((long)head * d.Npp + (krow - Nqp)) * hd + 4 * c4));
-                }
-                return val;
-            };
-            bf16x8 vf[DVS];
-            bf16x4 vf4 = zero4();
-            if (G::V16) vf4 = vload(g);
-            else {
+                for (int u = 0; u < ntc / 2; ++u) {
+                    f32x4 pv[2], ds[2];
 #pragma unroll
-                for (int s = 0; s < DVS; ++s) vf[s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
-            }
-            for (int u = 0; u < ntc / 2; ++u) {
-                f32x4 pv[2], ds[2];
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int lt = 2 * u + hh;
+                        // rows of this accumulator tile are queries 16*lt + 4g + j
+                        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
+                        f32x4 s = {l4.x, l4.y, l4.z, l4.w}, dp = fzero4();
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int lt = 2 * u + hh;
-                    // rows of this accumulator tile are queries 16*lt + 4g + j
-                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * lt + 4 * g);
-                    f32x4 s = {l4.x, l4.y, l4.z, l4.w}, dp = fzero4();
-#pragma unroll
-                    for (int ks = 0; ks < DKS; ++ks)
-                        s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), kf[ks], s);
-                    if (G::V16) {
-                        dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Oimg + (size_t)(16 * lt + r) * OROW + 8 * g), vf4, dp);
-                    } else {
-#pragma unroll
-                        for (int ks = 0; ks < DVS; ++ks)
-                            dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
-                    }
-                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
-                    const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
-                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
-                    const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float keep = 1.f;
-                        if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
-                            const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
-                            keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
-                        }
-                        float p, dsv;
-                        if (MASKED) {
-                            bool live;
-                            const float sv = classify_logit(s[j], kcls, rqs[j], live, ls[j]);
-                            const bool qok = rqs[j] != -1;                  // padding query rows: no P, no gradient
-                            p = qok ? __builtin_amdgcn_exp2f(sv) : 0.f;
-                            dsv = (live & qok) ? p * (dp[j] * keep - dls[j]) : 0.f;
+                        for (int ks = 0; ks < DKS; ++ks)
+                            s = mfma16(*reinterpret_cast<const bf16x8*>(Qimg + G::KR::off(16 * lt + r, 32 * ks + 8 * g)), kf[ks], s);
+                        if (G::V16) {
+                            dp = mfma16k16(*reinterpret_cast<const bf16x4*>(Oimg + (size_t)(16 * lt + r) * OROW + 8 * g), vf4, dp);
                         } else {
-                            // un-shifted block: every valid key is attended by every valid query -- P = 0 exactly where
-                            // either is padding, and dS = P * (...) vanishes with it
-                            const bool ok = kvalid & (rqs[j] != -1);
-                            p = ok ? __builtin_amdgcn_exp2f(s[j]) : 0.f;
-                            dsv = p * (dp[j] * keep - dls[j]);
+#pragma unroll
+                            for (int ks = 0; ks < DVS; ++ks)
+                                dp = mfma16(*reinterpret_cast<const bf16x8*>(Oimg + (size_t)(16 * lt + r) * OROW + (32 * ks + 8 * g) * 2), vf[ks], dp);
                         }
-                        pv[hh][j] = p * keep;
-                        ds[hh][j] = dsv;
-                        dtok[i] += dsv;
+                        const float4 d4 = *reinterpret_cast<const float4*>(del_s + 16 * lt + 4 * g);
+                        const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
+                        const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                        const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float keep = 1.f;
+                            if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
+                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                                keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
+                            }
+                            float p, dsv;
+                            if (CUT) {
+                                // a masked logit is the constant 0 (accumulator value ls[j]): it keeps its P, carries no gradient
+                                const bool live = (kcls == rqs[j]) | (kcls == -2);
+                                p = __builtin_amdgcn_exp2f(live ? s[j] : ls[j]);
+                                dsv = live ? p * (dp[j] * keep - dls[j]) : 0.f;
+                            } else {
+                                // no shift mask in effect: P = 0 wherever the key or the query row is padding (bias / -inf start)
+                                p = __builtin_amdgcn_exp2f(s[j]);
+                                dsv = p * (dp[j] * keep - dls[j]);
+                            }
+                            pv[hh][j] = p * keep;
+                            ds[hh][j] = dsv;
+                            dtok[i] += dsv;
+                        }
                     }
-                }
-                const bf16x8 pb = cat44(pack4(pv[0]), pack4(pv[1]));
-                const bf16x8 sb = cat44(pack4(ds[0]), pack4(ds[1]));
+                    const bf16x8 pb = cat44(pack4(pv[0]), pack4(pv[1]));
+                    const bf16x8 sb = cat44(pack4(ds[0]), pack4(ds[1]));
 #pragma unroll
-                for (int dd = 0; dd < DVT; ++dd) {
-                    const char* qrow_t = Qt + (size_t)(16 * dd + r) * TROW;
-                    const char* orow_t = Ot + (size_t)(16 * dd + r) * TROW;
-                    const bf16x8 aq = cat44(*reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 4 * g) * 2),
-                                            *reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 16 + 4 * g) * 2));
-                    const bf16x8 ao = cat44(*reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 4 * g) * 2),
-                                            *reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 16 + 4 * g) * 2));
-                    dkacc[i][dd] = mfma16(aq, sb, dkacc[i][dd]);
-                    dvacc[i][dd] = mfma16(ao, pb, dvacc[i][dd]);
-                }
-                if (AUG) {
-                    // The table gradients are signed sums of dS with heavy cancellation (each softmax row of dS sums
-                    // to zero), so dS enters this product as a bf16 hi + lo pair (qa is an exact one-hot).
-                    f32x4 lo[2];
+                    for (int dd = 0; dd < DVT; ++dd) {
+                        const char* qrow_t = Qt + (size_t)(16 * dd + r) * TROW;
+                        const char* orow_t = Ot + (size_t)(16 * dd + r) * TROW;
+                        const bf16x8 aq = cat44(*reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 4 * g) * 2),
+                                                *reinterpret_cast<const bf16x4*>(qrow_t + (32 * u + 16 + 4 * g) * 2));
+                        const bf16x8 ao = cat44(*reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 4 * g) * 2),
+                                                *reinterpret_cast<const bf16x4*>(orow_t + (32 * u + 16 + 4 * g) * 2));
+                        dkacc[i][dd] = mfma16(aq, sb, dkacc[i][dd]);
+                        dvacc[i][dd] = mfma16(ao, pb, dvacc[i][dd]);
+                    }
+                    if (AUG) {
+                        // The table gradients are signed sums of dS with heavy cancellation (each softmax row of dS sums
+                        // to zero), so dS enters this product as a bf16 hi + lo pair (qa is an exact one-hot).
+                        f32x4 lo[2];
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh)
+                        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) lo[hh][j] = ds[hh][j] - (float)(bf16_t)ds[hh][j];
-                    const bf16x8 sb_lo = cat44(pack4(lo[0]), pack4(lo[1]));
+                            for (int j = 0; j < 4; ++j) lo[hh][j] = ds[hh][j] - (float)(bf16_t)ds[hh][j];
+                        const bf16x8 sb_lo = cat44(pack4(lo[0]), pack4(lo[1]));
 #pragma unroll
-                    for (int dd = 0; dd < 2; ++dd) {
-                        const char* arow_t = Qt + (size_t)(16 * DVT + 16 * dd + r) * TROW;
-                        const bf16x8 aa = cat44(*reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 4 * g) * 2),
-                                                *reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 16 + 4 * g) * 2));
-                        dkaug[i][dd] = mfma16(aa, sb, dkaug[i][dd]);
-                        dkaug[i][dd] = mfma16(aa, sb_lo, dkaug[i][dd]);
+                        for (int dd = 0; dd < 2; ++dd) {
+                            const char* arow_t = Qt + (size_t)(16 * DVT + 16 * dd + r) * TROW;
+                            const bf16x8 aa = cat44(*reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 4 * g) * 2),
+                                                    *reinterpret_cast<const bf16x4*>(arow_t + (32 * u + 16 + 4 * g) * 2));
+                            dkaug[i][dd] = mfma16(aa, sb, dkaug[i][dd]);
+                            dkaug[i][dd] = mfma16(aa, sb_lo, dkaug[i][dd]);
+                        }
                     }
                 }
             }
-        }
+        };
+        if (MASKED && cut) compute(std::true_type{});
+        else compute(std::false_type{});
     }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -941,7 +984,9 @@ static int launch_dq(const MivpSwinDesc* d, const void* q, const void* k, const 
     const int nt = d->Nkp / 16;
     const int chunk = pick_chunk(nt, fixed, per_tile, ATTN_BWD_LDS_BUDGET);
     const size_t lds = fixed + per_tile * chunk;
-    auto kern = d->attn_drop_thr ? k_win_attn_bwd_dq<DKS, DVT, QPW, NW, true> : k_win_attn_bwd_dq<DKS, DVT, QPW, NW, false>;
+    const bool msk = d->has_mask != 0;
+    auto kern = d->attn_drop_thr ? (msk ? k_win_attn_bwd_dq<DKS, DVT, QPW, NW, true, true> : k_win_attn_bwd_dq<DKS, DVT, QPW, NW, true, false>)
+                                 : (msk ? k_win_attn_bwd_dq<DKS, DVT, QPW, NW, false, true> : k_win_attn_bwd_dq<DKS, DVT, QPW, NW, false, false>);
     MIVP_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, st, *d, chunk, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa,

@@ -240,6 +240,8 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
             else if (a < w0 + w1 + w2 - 1) val = td[k2 - (a - w0 - w1) + w2 - 1] - fold;
         } else if (m >= d.Nqp && m < d.Nqp + d.Np) {
             if (a < w0) val = ts[(long)head * d.Np + (m - d.Nqp)];
+        } else {
+            if (a < w0) val = MIVP_PAD_KEY_BIAS;                   // padding key: common.hpp
         }
         ka[((long)head * d.Nkp + m) * A + a] = (bf16_t)(val * MIVP_LOG2E);
     }
@@ -351,10 +353,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
     }
     // ---- key classes (classify_logit in common.hpp) ----
     for (int m = tid; m < Nkp; m += 64 * NW) {
-        int cls = -1;
-        if (m < d.Nq) cls = MASKED ? tok_rid[pw * Nqp + m] : 0;
-        else if (m >= Nqp && m < Nqp + d.Np) cls = -2;
-        ridk[m] = (uint8_t)(cls == -1 ? 255 : (cls == -2 ? 254 : cls));
+        // content key: region id; prompt and padding keys: 254 = never masked (padding keys are excluded by their bias)
+        ridk[m] = (uint8_t)((m < d.Nq && MASKED) ? tok_rid[pw * Nqp + m] : (m < d.Nq ? 0 : 254));
     }
     __syncthreads();
     // Most windows of a shifted block are not cut by the volume boundary: all their content tokens share one region id
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
                 for (int s = 0; s < DKS; ++s)
                     kfr[hh][s] = *reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * (2 * u + hh) + r, 32 * s + 8 * g));
             uint32_t kcl[2] = {0u, 0u};
-            if (MASK || TAIL) {
+            if (MASK) {
                 kcl[0] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u) + 4 * g);
                 kcl[1] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u + 1) + 4 * g);
             }
@@ -442,26 +442,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
                     f32x4 acc = negm[a];
 #pragma unroll
                     for (int s = 0; s < DKS; ++s) acc = mfma16(kfr[hh][s], qf[a][s], acc);
-                    const uint32_t kr = kcl[hh];
-                    if (!TAIL || t < nt_full) {
-                        if (MASK) {
+                    if (MASK) {
+                        const uint32_t kr = kcl[hh];
+                        if (!TAIL || t < nt_full) {
                             acc[0] = ((kr & 0xFFu) == rq[a]) ? acc[0] : negm[a][0];
                             acc[1] = (((kr >> 8) & 0xFFu) == rq[a]) ? acc[1] : negm[a][0];
                             acc[2] = (((kr >> 16) & 0xFFu) == rq[a]) ? acc[2] : negm[a][0];
                             acc[3] = ((kr >> 24) == rq[a]) ? acc[3] : negm[a][0];
+                        } else {                             // prompt / padding keys (254) are never masked
+                            const uint32_t k0 = kr & 0xFFu, k1 = (kr >> 8) & 0xFFu, k2 = (kr >> 16) & 0xFFu, k3 = kr >> 24;
+                            acc[0] = (k0 == rq[a] || k0 == 254u) ? acc[0] : negm[a][0];
+                            acc[1] = (k1 == rq[a] || k1 == 254u) ? acc[1] : negm[a][0];
+                            acc[2] = (k2 == rq[a] || k2 == 254u) ? acc[2] : negm[a][0];
+                            acc[3] = (k3 == rq[a] || k3 == 254u) ? acc[3] : negm[a][0];
                         }
-                    } else if (!MASK) {
-                        // no shift mask: content and prompt keys are all attended, only padding keys are excluded
-                        acc[0] = ((kr & 0xFFu) == 255u) ? -INFINITY : acc[0];
-                        acc[1] = (((kr >> 8) & 0xFFu) == 255u) ? -INFINITY : acc[1];
-                        acc[2] = (((kr >> 16) & 0xFFu) == 255u) ? -INFINITY : acc[2];
-                        acc[3] = ((kr >> 24) == 255u) ? -INFINITY : acc[3];
-                    } else {
-                        bool live;
-                        acc[0] = classify_logit_c<255, 254>(acc[0], (int)(kr & 0xFFu), (int)rq[a], live, negm[a][0]);
-                        acc[1] = classify_logit_c<255, 254>(acc[1], (int)((kr >> 8) & 0xFFu), (int)rq[a], live, negm[a][0]);
-                        acc[2] = classify_logit_c<255, 254>(acc[2], (int)((kr >> 16) & 0xFFu), (int)rq[a], live, negm[a][0]);
-                        acc[3] = classify_logit_c<255, 254>(acc[3], (int)(kr >> 24), (int)rq[a], live, negm[a][0]);
                     }
                     sv[a][hh] = acc;
                 }
