@@ -58,7 +58,7 @@ def traffic_bytes():
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     try:
         with open(path) as f:
-            return float(json.load(f)["conv3d_dec2"]["hbm_bytes_per_launch"])
+            return float(json.load(f)["conv3d_dec2_6x6"]["hbm_bytes_per_launch"])   # the brick form the model runs
     except (OSError, KeyError, ValueError):
         return None
 

@@ -78,13 +78,15 @@ typedef struct MivpSwinDesc {
 
 /* gather + LayerNorm + q/k/v projections  (swin_block.py:205-214, window_attention.py:42-47)
  *   x [B, vol_in, C] bf16;  ln_w, ln_b [C] f32;  wqkv [3C][C] bf16 (to_q, to_k, to_v stacked)
- *   q, k, v [B*P][heads][Nqp][hd] bf16 ; q is pre-multiplied by q_scale ; slots >= Nq are zero */
+ *   q, k, v [B*P][heads][Nqp][hd] bf16 ; q is pre-multiplied by q_scale ; slots >= Nq are zero.
+ *   k is stored multiplied by log2(e): the attention kernels keep logits in log2 units so that S = K'Q'^T feeds
+ *   v_exp_f32 directly (the gradient entries below still take / return dk w.r.t. the un-scaled k).           */
 int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_src,
                       const float* ln_w, const float* ln_b, const void* wqkv,
                       void* q, void* k, void* v, mivp_stream_t stream);
 
 /* prompt tokens -> LayerNorm -> to_k / to_v, once per block
- *   prompt [Np][C] f32 (the nn.Parameter) -> kp, vp [heads][Npp][hd] bf16 (rows >= Np zero)
+ *   prompt [Np][C] f32 (the nn.Parameter) -> kp, vp [heads][Npp][hd] bf16 (rows >= Np zero; kp x log2(e) like k)
  *   yln [Np][C] f32: the normalised prompt, saved for backward                            */
 int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* ln_w, const float* ln_b,
                        const void* wqkv, void* kp, void* vp, float* yln, mivp_stream_t stream);
@@ -95,12 +97,15 @@ int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* 
  *   scores (scaled), or NULL when Np == 0.
  *   Because the bias is a sum of three terms that each depend on ONE slot coordinate of the query, it
  *   equals <onehot(query coords), table values at the key coords>: the kernel emits that as extra K
- *   columns of the QK^T MFMA:   qa [Nqp][augp] bf16 (query one-hots),  ka [heads][Nkp][augp] bf16. */
+ *   columns of the QK^T MFMA:   qa [Nqp][augp] bf16 (query one-hots),  ka [heads][Nkp][augp] bf16 (x log2(e)).
+ *   Padding key rows (Nq..Nqp-1 and the unused prompt rows) carry -30000 in the w0 query-h columns: every valid query
+ *   sees that logit there, P underflows to exactly 0 and the attention kernels never test for padding keys.      */
 int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, const float* t_d,
                      const float* ts, void* qa, void* ka, mivp_stream_t stream);
 
 /* softmax((q k^T + bias) * mask) v per (window, head)  (window_attention.py:49-59)
- *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 */
+ *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 (natural log)
+ *   tok_rid [P][Nqp] int32: shift-mask region id of every window slot, 0 <= id < 254 (27 regions in 3D)        */
 int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
                       const void* kp, const void* vp, const void* qa, const void* ka,
                       const int32_t* tok_rid, void* o, float* lse, mivp_stream_t stream);

@@ -234,6 +234,39 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
             rv[i][nt] = (residual && ok[i] && co < d.Cout) ? ld4(residual + voff[i] + co) : zero4();
         }
     }
+    // Wide stores: a lane's natural piece is 8 bytes (4 channels of one voxel), so one store instruction would write a
+    // third of every 96-byte voxel row and leave the L2 to merge partial lines (measured: up to 1.56x the output bytes
+    // in 64-byte write requests).  When the workgroup's channel slice is whole, each wave stages its TPW x 16 voxels x
+    // BN channels in its own corner of the (now idle) LDS and writes 16 bytes per lane, whole rows at a time.
+    const bool wide = (co_base + BN <= d.Cout) && (d.Cout % 8 == 0);
+    if (wide) {
+        char* ost = smem + (size_t)wave * (TPW * 16 * BN * 2);    // the last chunk's barrier has passed: LDS is free
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                f32x4 v = acc[i][nt] + bv[nt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)rv[i][nt][j];
+                *reinterpret_cast<bf16x4*>(ost + ((i * 16 + r) * BN + 16 * nt + 4 * g) * 2) = pack4(v);
+            }
+        // the wave reads back only what it wrote itself: no barrier
+        constexpr int SEG = BN * 2 / 16;                          // 16-byte pieces per voxel
+        const long row0 = (((long)b * H + (h0 + th)) * W + (w0 + tw0)) * D + d0;
+#pragma unroll
+        for (int p0 = 0; p0 < TPW * 16 * SEG; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < TPW * 16 * SEG) {
+                const int vox = p / SEG, seg = p - vox * SEG, i = vox >> 4, rr = vox & 15;
+                const bool inside = (h0 + th) < H && (w0 + tw0 + i) < W && (d0 + rr) < D;
+                if (inside) {
+                    const bf16x8 piece = *reinterpret_cast<const bf16x8*>(ost + (size_t)vox * (BN * 2) + 16 * seg);
+                    st8(y + (row0 + (long)i * D + rr) * d.Cout + co_base + 8 * seg, piece);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         if (!ok[i]) continue;
