@@ -422,19 +422,49 @@ def upcat(x, skip, scale, align_corners=False):
 # phase-1 proxy heads (--training-mode self_supervised_learning_encoder, swin_unetr.py:64-83,180-222)
 # ----------------------------------------------------------------------------------------------
 class _InstanceNormActFn(torch.autograd.Function):
-    """nn.InstanceNorm3d (no affine) + nn.LeakyReLU(0.01) on channels-last bf16."""
+    """nn.InstanceNorm3d (no affine) [+ nn.LeakyReLU(0.01)] on channels-last bf16."""
 
     @staticmethod
-    def forward(ctx, x, eps):
-        y, saved = ops.instance_norm_act(x, eps, True)
+    def forward(ctx, x, eps, lrelu=True):
+        y, saved = ops.instance_norm_act(x, eps, lrelu)
         ctx.save_for_backward(x)
         ctx.saved = saved
+        ctx.lrelu = lrelu
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.instance_norm_act_backward(x, dy.contiguous(), ctx.saved, True), None
+        return ops.instance_norm_act_backward(x, dy.contiguous(), ctx.saved, ctx.lrelu), None, None
+
+
+def _conv1x1_weights(cache: WeightCache, key, conv):
+    """A 1^3 convolution run by the 3^3 kernels: its weight sits on the centre tap (autograd slices the gradient back)."""
+    def build():
+        w27 = torch.nn.functional.pad(conv.weight.detach(), (1, 1, 1, 1, 1, 1))
+        return ops.pack_conv_weight(w27), ops.pack_conv_weight_dgrad(w27)
+    return cache.get(key, [conv.weight], build)
+
+
+def unetr_basic_block(owner, key, block, x):
+    """MONAI ``UnetrBasicBlock`` (stride 1, norm 'instance', LeakyReLU 0.01) on channels-last bf16:
+    conv 3^3 -> IN -> LReLU -> conv 3^3 -> IN [-> + (IN(conv 1^3(x)) | x)] -> LReLU."""
+    lay = block.layer
+    cout = lay.conv1.conv.out_channels
+    out = conv3d_plain(owner, f"{key}.c1", lay.conv1.conv, x)
+    out = _InstanceNormActFn.apply(out, float(lay.norm1.eps), True)
+    out = conv3d_plain(owner, f"{key}.c2", lay.conv2.conv, out)
+    if not block.res_block:
+        return _InstanceNormActFn.apply(out, float(lay.norm2.eps), True)
+    out = _InstanceNormActFn.apply(out, float(lay.norm2.eps), False)
+    if hasattr(lay, "conv3"):
+        wp, wd = _conv1x1_weights(owner._wcache, f"{key}.c3", lay.conv3.conv)
+        w27 = torch.nn.functional.pad(lay.conv3.conv.weight, (1, 1, 1, 1, 1, 1))
+        res = _ConvFn.apply(x, None, w27, None, wp, wd, None, cout)
+        res = _InstanceNormActFn.apply(res, float(lay.norm3.eps), False)
+    else:
+        res = x[..., :cout]
+    return torch.nn.functional.leaky_relu(out + res, 0.01)
 
 
 class _PointwiseConvFn(torch.autograd.Function):
@@ -472,7 +502,7 @@ def reconstruction_head(owner, head: torch.nn.Sequential, x):
     while i + 3 < len(mods):
         conv, norm, act, up = mods[i:i + 4]
         x = conv3d_plain(owner, f"rec{stage}", conv, x)
-        x = _InstanceNormActFn.apply(x, float(norm.eps))
+        x = _InstanceNormActFn.apply(x, float(norm.eps), True)
         x = upcat(x, None, tuple(int(s) for s in up.scale_factor), align_corners=True)
         i += 4
         stage += 1

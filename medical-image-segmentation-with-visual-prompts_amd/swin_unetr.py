@@ -199,6 +199,43 @@ class _ConvHolder(nn.Sequential):
         self.add_module("conv", nn.Conv3d(cin, cout, 3, 1, padding=1, bias=True))
 
 
+class _BareConv(nn.Sequential):
+    """State-dict twin of MONAI ``get_conv_layer(..., conv_only=False, act=None, norm=None)``: child ``conv``, no bias."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.add_module("conv", nn.Conv3d(cin, cout, k, 1, padding=k // 2, bias=False))
+
+
+class _UnetBlockLayer(nn.Module):
+    """MONAI ``UnetResBlock`` / ``UnetBasicBlock`` (networks/blocks/dynunet_block.py) at stride 1 with norm 'instance':
+    the attribute names are MONAI's, the arithmetic runs in ``functional.unetr_basic_block``."""
+
+    def __init__(self, cin, cout, res_block):
+        super().__init__()
+        self.conv1 = _BareConv(cin, cout, 3)
+        self.conv2 = _BareConv(cout, cout, 3)
+        self.lrelu = nn.LeakyReLU(0.01, inplace=True)
+        self.norm1 = nn.InstanceNorm3d(cout)
+        self.norm2 = nn.InstanceNorm3d(cout)
+        if res_block:
+            self.downsample = cin != cout
+            if self.downsample:
+                self.conv3 = _BareConv(cin, cout, 1)
+                self.norm3 = nn.InstanceNorm3d(cout)
+
+
+class UnetrBasicBlock(nn.Module):
+    """Stand-in for MONAI ``UnetrBasicBlock(spatial_dims=3, kernel_size=3, stride=1, norm_name='instance', res_block=...)``
+    (swin_unetr.py:248-289 with ``unetr_res_block: 'full'``).  MONAI is not importable here: structure and
+    state-dict names are restated from its documented source, parity unpinned at that boundary."""
+
+    def __init__(self, in_channels, out_channels, res_block):
+        super().__init__()
+        self.res_block = bool(res_block)
+        self.layer = _UnetBlockLayer(in_channels, out_channels, self.res_block)
+
+
 class SwinUpBlock(nn.Module):
     """Decoder stage (swin_unetr/unet_blocks.py:11-92): upsample, crop+concat, BN, LeakyReLU, conv 3^3,
     two Swin blocks."""
@@ -306,16 +343,24 @@ class SwinUnetR(nn.Module):
         c = self.conf
         hc = list(c.hidden_channels)
         depth = c.depth_unet
-        if c.unetr_up_block != "swin" or c.unetr_res_block == "full":
+        if c.unetr_up_block != "swin":
             raise NotImplementedError(
-                "mivp_amd: the MONAI UnetrUpBlock / UnetrBasicBlock options are not built (the UnetrUpBlock path "
-                "is not runnable in the reference either, SURVEY 8 a16); use unetr_up_block='swin' and "
-                "unetr_res_block in ('none', 'simple')")
+                "mivp_amd: the MONAI UnetrUpBlock option is not built (that path is not runnable in the reference "
+                "either: it is called with three arguments and takes two, SURVEY 8 a16); use unetr_up_block='swin'")
         self._build_encoder()
         dec_in = [hc[i + 1] for i in range(depth)][::-1]       # channels entering each decoder stage
         dec_out = [hc[i] for i in range(depth)][::-1]
-        self.bottleneck = nn.Conv3d(dec_in[0], dec_in[0], 3, 1, padding=1)
-        if c.unetr_res_block == "simple":
+        if c.unetr_res_block == "full":
+            # conf.basic_block_res is read unguarded, as in the reference (swin_unetr.py:256,277,288): it is not a yml key
+            self.bottleneck = UnetrBasicBlock(dec_in[0], dec_in[0], c.basic_block_res)
+            self.residual_blocks = nn.ModuleList(
+                [UnetrBasicBlock(dec_out[i], dec_out[i], c.basic_block_res) for i in range(depth)]
+                + [UnetrBasicBlock(c.input_channels, dec_out[-1], c.basic_block_res)])
+        else:
+            self.bottleneck = nn.Conv3d(dec_in[0], dec_in[0], 3, 1, padding=1)
+        if c.unetr_res_block == "full":
+            pass
+        elif c.unetr_res_block == "simple":
             self.residual_blocks = nn.ModuleList(
                 [nn.Conv3d(dec_out[i], dec_out[i], 3, 1, padding=1) for i in range(depth)]
                 + [nn.Conv3d(c.input_channels, dec_out[-1], 3, 1, padding=1)])
@@ -381,15 +426,23 @@ class SwinUnetR(nn.Module):
         low-resolution output, i.e. skips ``output_layer`` (the x2 trilinear upsample)."""
         c = self.conf
         depth = c.depth_unet
-        dec = Fn.conv3d_plain(self, "bottleneck", self.bottleneck, feats[0], residual=feats[0])
+        if c.unetr_res_block == "full":
+            dec = Fn.unetr_basic_block(self, "bottleneck", self.bottleneck, feats[0]) + feats[0]
+        else:
+            dec = Fn.conv3d_plain(self, "bottleneck", self.bottleneck, feats[0], residual=feats[0])
         for j in range(depth):
             skip = feats[j + 1]
             if c.unetr_res_block == "simple":
                 skip = Fn.conv3d_plain(self, f"res{j}", self.residual_blocks[j], skip)
+            elif c.unetr_res_block == "full":
+                skip = Fn.unetr_basic_block(self, f"res{j}", self.residual_blocks[j], skip)
             dec = self.decoder_blocks[j](dec, skip, self._prompts("dec", j))
         if c.unetr_res_block == "none":
             return Fn.upcat(dec, None, (2, 2, 2)) if upsample_output else dec
-        skip = Fn.conv3d_plain(self, f"res{depth}", self.residual_blocks[depth], Fn.to_channels_last(feats[-1]))
+        if c.unetr_res_block == "full":
+            skip = Fn.unetr_basic_block(self, f"res{depth}", self.residual_blocks[depth], Fn.to_channels_last(feats[-1]))
+        else:
+            skip = Fn.conv3d_plain(self, f"res{depth}", self.residual_blocks[depth], Fn.to_channels_last(feats[-1]))
         return self.output_layer(dec, skip, self._prompts("out", 0))
 
     def forward(self, x):

@@ -100,10 +100,33 @@ def _conv_state(sd, prefix, cin, cout, k, gen):
     sd[f"{prefix}bias"] = _uniform((cout,), b, gen)
 
 
+def _basic_block_state(sd, prefix, cin, cout, res_block, gen):
+    """MONAI ``UnetrBasicBlock`` (``.layer`` = ``UnetResBlock`` | ``UnetBasicBlock``, dynunet_block.py): bias-free convs
+    wrapped in ``Convolution`` (child ``conv``); InstanceNorm3d without affine has no state.  MONAI is absent: the
+    structure is restated from its documented source, parity unpinned."""
+    for name, ci, k in (("conv1", cin, 3), ("conv2", cout, 3)):
+        sd[f"{prefix}layer.{name}.conv.weight"] = _uniform((cout, ci, k, k, k), 1 / math.sqrt(ci * k ** 3), gen)
+    if res_block and cin != cout:
+        sd[f"{prefix}layer.conv3.conv.weight"] = _uniform((cout, cin, 1, 1, 1), 1 / math.sqrt(cin), gen)
+
+
+def basic_block_forward(x: Tensor, sd, prefix: str, res_block: bool) -> Tensor:
+    """MONAI ``UnetResBlock.forward`` / ``UnetBasicBlock.forward`` with norm 'instance' and LeakyReLU(0.01), stride 1."""
+    out = F.conv3d(x, sd[f"{prefix}layer.conv1.conv.weight"], None, padding=1)
+    out = F.leaky_relu(F.instance_norm(out, eps=1e-5), 0.01)
+    out = F.instance_norm(F.conv3d(out, sd[f"{prefix}layer.conv2.conv.weight"], None, padding=1), eps=1e-5)
+    if res_block:
+        residual = x
+        if f"{prefix}layer.conv3.conv.weight" in sd:
+            residual = F.instance_norm(F.conv3d(x, sd[f"{prefix}layer.conv3.conv.weight"], None), eps=1e-5)
+        out = out + residual
+    return F.leaky_relu(out, 0.01)
+
+
 def random_state(conf: Namespace, seed: int = 0) -> "OrderedDict[str, Tensor]":
     """A randomly initialised state dict with the reference's key names and
     shapes for the default block options
-    (``unetr_up_block == 'swin'``, ``unetr_res_block in ('none', 'simple')``).
+    (``unetr_up_block == 'swin'``, ``unetr_res_block in ('none', 'simple', 'full')``).
     Init distributions follow torch defaults; exact values never matter because
     parity runs always load the same dict on both sides."""
     gen = torch.Generator().manual_seed(seed)
@@ -142,9 +165,15 @@ def random_state(conf: Namespace, seed: int = 0) -> "OrderedDict[str, Tensor]":
         sd[f"encoder_blocks.{i}.merge.norm.bias"] = torch.zeros(k * hc[i])
         sd[f"encoder_blocks.{i}.merge.reduction.weight"] = _uniform((hc[i + 1], k * hc[i]), 1 / math.sqrt(k * hc[i]), gen)
     if has_decoder:
-        _conv_state(sd, "bottleneck.", hc[depth], hc[depth], 3, gen)
         in_chs = [hc[i] for i in range(depth)][::-1]
         out_chs = [hc[i + 1] for i in range(depth)][::-1]
+        if conf.unetr_res_block == "full":
+            _basic_block_state(sd, "bottleneck.", hc[depth], hc[depth], conf.basic_block_res, gen)
+            for i in range(depth):
+                _basic_block_state(sd, f"residual_blocks.{i}.", in_chs[i], in_chs[i], conf.basic_block_res, gen)
+            _basic_block_state(sd, f"residual_blocks.{depth}.", conf.input_channels, in_chs[-1], conf.basic_block_res, gen)
+        else:
+            _conv_state(sd, "bottleneck.", hc[depth], hc[depth], 3, gen)
         if conf.unetr_res_block == "simple":
             for i in range(depth):
                 _conv_state(sd, f"residual_blocks.{i}.", in_chs[i], in_chs[i], 3, gen)
@@ -181,10 +210,9 @@ class OracleSwinUnetR:
     def __init__(self, conf: Namespace, sd: Optional[Dict[str, Tensor]] = None, seed: int = 0):
         if conf.training_mode not in TRAINING_MODES:
             raise ValueError(f"Training mode {conf.training_mode} not available!")
-        if conf.unetr_up_block != "swin" or conf.unetr_res_block == "full":
+        if conf.unetr_up_block != "swin":
             raise NotImplementedError(
-                "MONAI UnetrBasicBlock/UnetrUpBlock paths have no oracle (MONAI absent; "
-                "the UnetrUpBlock path is not runnable in the reference, SURVEY a16)")
+                "the MONAI UnetrUpBlock path has no oracle (MONAI absent; not runnable in the reference, SURVEY a16)")
         self.conf = conf
         self.sd = sd if sd is not None else random_state(conf, seed)
 
@@ -212,7 +240,10 @@ class OracleSwinUnetR:
         conf, sd = self.conf, self.sd
         depth = conf.depth_unet
         c0 = feats[0]
-        dec = F.conv3d(c0, sd["bottleneck.weight"], sd["bottleneck.bias"], padding=1) + c0
+        if conf.unetr_res_block == "full":
+            dec = basic_block_forward(c0, sd, "bottleneck.", conf.basic_block_res) + c0
+        else:
+            dec = F.conv3d(c0, sd["bottleneck.weight"], sd["bottleneck.bias"], padding=1) + c0
         for j in range(depth):
             if conf.use_decoder_prompting:
                 pr = (sd[f"prompt_tokens.dec.{2 * j}"], sd[f"prompt_tokens.dec.{2 * j + 1}"])
@@ -221,6 +252,8 @@ class OracleSwinUnetR:
             skip = feats[j + 1]
             if conf.unetr_res_block == "simple":
                 skip = F.conv3d(skip, sd[f"residual_blocks.{j}.weight"], sd[f"residual_blocks.{j}.bias"], padding=1)
+            elif conf.unetr_res_block == "full":
+                skip = basic_block_forward(skip, sd, f"residual_blocks.{j}.", conf.basic_block_res)
             strides = (2, 2, 1 if j < depth - 1 else 2)
             dec = S.up_block(dec, skip, pr, sd, f"decoder_blocks.{j}.", strides, conf.attn_window_size,
                              conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb)
@@ -230,7 +263,10 @@ class OracleSwinUnetR:
             pr = (sd["prompt_tokens.out.0"], sd["prompt_tokens.out.1"])
         else:
             pr = (None, None)
-        skip = F.conv3d(feats[-1], sd[f"residual_blocks.{depth}.weight"], sd[f"residual_blocks.{depth}.bias"], padding=1)
+        if conf.unetr_res_block == "full":
+            skip = basic_block_forward(feats[-1], sd, f"residual_blocks.{depth}.", conf.basic_block_res)
+        else:
+            skip = F.conv3d(feats[-1], sd[f"residual_blocks.{depth}.weight"], sd[f"residual_blocks.{depth}.bias"], padding=1)
         return S.up_block(dec, skip, pr, sd, "output_layer.", (2, 2, 2), conf.attn_window_size,
                           conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb)
 

@@ -414,3 +414,31 @@ def test_ssl_encoder_mode_with_proxy_heads():
     assert len(enc) > 100
     for n, p in enc:
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+@pytest.mark.parametrize("res_block,mode,ep,dp", [(True, "self_supervised_learning_all", True, True),
+                                                 (False, "supervised_learning_decoder", False, False)])
+def test_unetr_res_block_full(res_block, mode, ep, dp):
+    """``unetr_res_block: 'full'``: MONAI ``UnetrBasicBlock`` on the bottleneck, every skip and the input
+    volume, a SwinUpBlock as output layer.  Forward and all parameter gradients against the oracle's restatement of the
+    MONAI block (MONAI itself is absent: parity unpinned at that boundary), state-dict names of the MONAI modules."""
+    import mivp_amd
+    from mivp_amd import train
+    from oracle.unetr_ref import OracleSwinUnetR, random_state
+    conf, _, _ = train.make_conf("tiny")
+    conf.training_mode = mode
+    conf.use_encoder_prompting, conf.use_decoder_prompting = ep, dp
+    conf.unetr_res_block = "full"
+    conf.basic_block_res = res_block
+    size, batch = 32, 2
+    sd = round_weights(random_state(conf, seed=21))
+    assert "residual_blocks.0.layer.conv1.conv.weight" in sd and "bottleneck.layer.conv2.conv.weight" in sd
+    assert ("residual_blocks.3.layer.conv3.conv.weight" in sd) == res_block
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(batch, conf.input_channels, size, size, size, generator=g)
+    gouts = {"latent_outputs": torch.randn(batch, conf.hidden_channels[0], size, size, size, generator=g) / size ** 1.5}
+    if mode.startswith("supervised"):
+        gouts["seg_pred"] = torch.randn(batch, conf.output_channels_pretrain, size, size, size, generator=g) / size ** 1.5
+    trainable = OracleSwinUnetR(conf, sd).trainable_keys()
+    # instance norms over 32-256 voxels at the deep stages: same conditioning regime as the 16^3 BatchNorm fixtures
+    _check_all_gradients(conf, sd, x, gouts, trainable, 2.5e-2)
