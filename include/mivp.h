@@ -357,6 +357,18 @@ int mivp_uphead_fwd(const void* x, const void* wf, const float* bias, int32_t B,
  * sums of D give S = sum_{u in bounds} dy[u - tap][co]: the (G, S) of mivp_conv3d_wgrad_rows. */
 int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout,
                         void* D, int32_t ldD, mivp_stream_t stream);
+/* BatchNorm affine folded into the head conv (swin_unetr.py:229-237): wf bf16 [16*ceil(27*Cout/16)][64], row tap*Cout + co
+ * = ( conv_w[co][c][tap] * scale[c]  for c < Cin | sum_c conv_w[co][c][tap] * shift[c] | 0 ... );  Cin < 64 */
+int mivp_uphead_fold(const float* conv_w, const float* scale, const float* shift, int32_t Cout, int32_t Cin, void* wf,
+                     mivp_stream_t stream);
+
+/* the four parameter gradients of the (BatchNorm -> conv 3^3) head from the (G, S) sums of mivp_uphead_adjoint +
+ * mivp_gemm_tn (or mivp_conv3d_wgrad_rows): element (co, tap, ci) of G at G[co*gs_co + tap*gs_tap + ci], (co, tap) of S
+ * at S[co*ss_co + tap*ss_tap];  dW [Cout][Cin][27], db [Cout], dgamma / dbeta [Cin] (autograd of swin_unetr.py:229-237) */
+int mivp_head_grads(const float* G, int64_t gs_co, int64_t gs_tap, const float* S, int64_t ss_co, int64_t ss_tap,
+                    const float* conv_w, const float* scale, const float* shift, const float* mean_rstd, int32_t Cout,
+                    int32_t Cin, float* dW, float* db, float* dgamma, float* dbeta, mivp_stream_t stream);
+
 /* gradient w.r.t. x [B,h,w,d,C] (bf16) through upsample -> BatchNorm -> conv, all at low resolution:
  *   D with ldD == 64; wc bf16 [16*ceil(C/16)][64] = conv weight as [c][tap*Cout + co] (zero padded);
  *   coef f32 [4][C] = (BN scale | sum(dz)/N | rstd*sum(dz*xhat)/N | batch mean), rows 1-2 zero for eval-mode BN */

@@ -44,6 +44,21 @@ def to_channels_last(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
     return y.to(BF16).contiguous()
 
 
+# BatchNorm's ``num_batches_tracked += 1`` is a 5 us kernel per layer: the increments of one forward are collected and
+# issued as ONE multi-tensor add when the model's forward returns (SwinUnetR.forward calls flush_counters()).
+_pending_counters = []
+
+
+def bump_counter(t: torch.Tensor):
+    _pending_counters.append(t)
+
+
+def flush_counters():
+    if _pending_counters:
+        torch._foreach_add_(_pending_counters, 1)
+        _pending_counters.clear()
+
+
 class WeightCache:
     """key -> kernel-ready tensors, rebuilt when any source parameter changed."""
 
@@ -79,7 +94,7 @@ class _PatchEmbedFn(torch.autograd.Function):
                                    training=training, momentum=bn.momentum if bn.momentum is not None else 0.1,
                                    return_stats=True)
         if training:
-            bn.num_batches_tracked += 1
+            bump_counter(bn.num_batches_tracked)
         ctx.save_for_backward(x, conv_w, conv_b, *stats)
         ctx.training = training
         return y
@@ -104,7 +119,7 @@ def patch_embed(owner, conv, bn, x):
                             bn.bias.detach().float().contiguous(), bn.eps, bn.running_mean, bn.running_var,
                             training=training, momentum=bn.momentum if bn.momentum is not None else 0.1)
         if training:
-            bn.num_batches_tracked += 1
+            bump_counter(bn.num_batches_tracked)
     return y
 
 
@@ -295,7 +310,7 @@ class _BnActConvFn(torch.autograd.Function):
             scale, shift, mean_rstd = ops.bn_batch_stats(
                 x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
                 bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
-            bn.num_batches_tracked += 1
+            bump_counter(bn.num_batches_tracked)
         else:
             scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
         cout = conv_w.shape[0]
@@ -365,7 +380,7 @@ class _UpHeadFn(torch.autograd.Function):
             scale, shift, mean_rstd = ops.uphead_batch_stats(
                 x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
                 bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
-            bn.num_batches_tracked += 1
+            bump_counter(bn.num_batches_tracked)
         else:
             scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
         cout = conv_w.shape[0]
@@ -380,10 +395,10 @@ class _UpHeadFn(torch.autograd.Function):
         x, scale, shift, mean_rstd, conv_w = ctx.saved_tensors
         g = ctx.needs_input_grad
         if g[0]:
-            G, S, D = ops.uphead_gs(x, dy, ctx.cout, keep_d=True)
+            G, S, D = ops.uphead_gs(x, dy, ctx.cout, keep_d=True, raw=True)
         else:
-            G, S = ops.uphead_gs(x, dy, ctx.cout)
-        dw, db, dgamma, dbeta = ops.head_grads_from_gs(G, S, conv_w, scale, shift, mean_rstd)
+            G, S = ops.uphead_gs(x, dy, ctx.cout, raw=True)
+        dw, db, dgamma, dbeta = ops.head_grads_fused(G, S, conv_w, scale, shift, mean_rstd)
         dx = ops.uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, ctx.training) if g[0] else None
         return (dx, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None, db if g[4] else None, None)
 

@@ -174,12 +174,10 @@ def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None
 def uphead_fold(conv_w, scale, shift):
     """BatchNorm affine folded into the head conv: bf16 [Mp][64], row tap*Cout + co = (w*scale | sum_c w*shift | 0)."""
     cout, cin = conv_w.shape[0], conv_w.shape[1]
-    wt = conv_w.detach().float().reshape(cout, cin, 27).permute(2, 0, 1)                 # [tap, co, c]
-    mp = round_up(27 * cout, 16)
-    wf = torch.zeros((mp, 64), dtype=torch.float32, device=conv_w.device)
-    wf[:27 * cout, :cin] = (wt * scale.view(1, 1, cin)).reshape(27 * cout, cin)
-    wf[:27 * cout, cin] = (wt * shift.view(1, 1, cin)).sum(-1).reshape(27 * cout)
-    return wf.to(BF16).contiguous()
+    wf = torch.empty((round_up(27 * cout, 16), 64), dtype=BF16, device=conv_w.device)
+    L.call("mivp_uphead_fold", L.ptr(conv_w.detach().float().contiguous()), L.ptr(scale), L.ptr(shift), C.c_int32(cout),
+           C.c_int32(cin), L.ptr(wf), L.stream())
+    return wf
 
 
 def uphead_forward(x, wf, conv_b, cout):
@@ -193,7 +191,7 @@ def uphead_forward(x, wf, conv_b, cout):
     return y
 
 
-def uphead_gs(x, dy, cout, keep_d=False):
+def uphead_gs(x, dy, cout, keep_d=False, raw=False):
     """(G, S) of the head as conv3d_wgrad_rows defines them, from the low-res x and dy [B,2h,2w,2d,cout] f32:
     G[co, tap, c] = sum_u dy[u - tap][co] * upsample(x)[u][c],  S[co, tap] = sum_{u in bounds} dy[u - tap][co].
     ``keep_d`` also returns the adjoint tensor D [T, 64] (for uphead_dx)."""
@@ -206,9 +204,26 @@ def uphead_gs(x, dy, cout, keep_d=False):
     L.call("mivp_uphead_adjoint", L.ptr(dy), C.c_int32(dy.shape[-1]), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d),
            C.c_int32(cout), L.ptr(D), C.c_int32(ld), L.stream())
     G = gemm_tn(D, operand_rows(ld), x, operand_rows(Cc), T, 27 * cout, Cc)                 # [tap*cout + co][c]
-    S = _colsum_bf16(D)[:27 * cout]
-    G, S = G.view(27, cout, Cc).permute(1, 0, 2).contiguous(), S.view(27, cout).t().contiguous()
+    S = _colsum_bf16(D)
+    if raw:                                                   # tap-major, as produced: for head_grads_fused
+        return (G, S, D) if keep_d else (G, S)
+    G, S = G.view(27, cout, Cc).permute(1, 0, 2).contiguous(), S[:27 * cout].view(27, cout).t().contiguous()
     return (G, S, D) if keep_d else (G, S)
+
+
+def head_grads_fused(G, S, conv_w, scale, shift, mean_rstd):
+    """head_grads_from_gs on the tap-major (G [27*Cout][Cin], S [>= 27*Cout]) of ``uphead_gs(..., raw=True)``: one
+    single-workgroup kernel instead of ~12 tiny tensor ops."""
+    cout, cin = conv_w.shape[0], conv_w.shape[1]
+    dev = conv_w.device
+    dW = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(cin, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(cin, dtype=torch.float32, device=dev)
+    L.call("mivp_head_grads", L.ptr(G), C.c_int64(G.shape[1]), C.c_int64(cout * G.shape[1]), L.ptr(S), C.c_int64(1),
+           C.c_int64(cout), L.ptr(conv_w.detach().float().contiguous()), L.ptr(scale), L.ptr(shift), L.ptr(mean_rstd),
+           C.c_int32(cout), C.c_int32(cin), L.ptr(dW), L.ptr(db), L.ptr(dgamma), L.ptr(dbeta), L.stream())
+    return dW, db, dgamma, dbeta
 
 
 def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training):

@@ -448,6 +448,12 @@ class SwinUnetR(nn.Module):
     def forward(self, x):
         """x: float [B, Cin, H, W, D] on the GPU -> dict as the reference (swin_unetr.py:129-144);
         volumes in the dict are channels-first *views* of channels-last storage."""
+        try:
+            return self._forward(x)
+        finally:
+            Fn.flush_counters()                      # the BatchNorm step counters of this forward, one launch
+
+    def _forward(self, x):
         Fn.require_device(x)
         mode = self.conf.training_mode
         feats = self.forward_swin_transformer(x)
