@@ -48,10 +48,20 @@ template <> struct BrickOf<8> { using G = HaloGeom<4, 8, 4>; };
 template <> struct BrickOf<4> { using G = HaloGeom<4, 4, 4>; };
 template <> struct BrickOf<6> { using G = HaloGeom<6, 6, 3>; };
 
+// 16 zero bytes in global memory: the LDS-DMA source of halo pieces outside the volume
+__device__ __attribute__((aligned(16))) unsigned int g_halo_zero[4] = {0u, 0u, 0u, 0u};
+
+// one 16-byte global -> LDS DMA per lane (global_load_lds_dwordx4): no VGPR destination, no ds_write; the LDS address is
+// wave-uniform base + lane * 16, so the images below are laid out lane-linearly and masked lanes write nothing
+MIVP_DEV void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 MIVP_DEV int halo_off(int row, int half) { return row * 32 + (half << 4); }
 MIVP_DEV int wswz(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
-template <int NTN, int BRICK>
+template <int NTN, int BRICK, bool PRO>
 __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ wh, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
         }
     }
     const int nchunks = Cin / 16;
-    if (d.pro_affine) {
+    if (PRO) {
         for (int c = tid; c < Cin; c += HTHREADS) { aff[c] = scale[c]; aff[Cin + c] = shift[c]; }
         __syncthreads();
     }
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
         for (int u = 0; u < HPIECES; ++u) {
             if (hdst[u] < 0) continue;
             bf16x8 v = hsrc[u] >= 0 ? hreg[u] : zero8();
-            if (d.pro_affine && hsrc[u] >= 0) {
+            if (PRO && hsrc[u] >= 0) {
                 const int c0 = 16 * fetched_chunk + 8 * ((tid + HTHREADS * u) & 1);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -153,6 +163,33 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
         }
     };
 
+    // LDS-DMA staging (every call without the fused prologue): piece p of the halo image lives at byte 16 p, so the 64
+    // pieces of one wave-instruction are contiguous; the weight image's per-row chunk swizzle moves to the SOURCE
+    // address (slot s of row holds chunk s ^ f(row)).  No staging registers, no VGPR -> LDS pass, no vmcnt waits inside
+    // the chunk: the DMAs of chunk c+1 are issued at the top of chunk c and retired by the wait + barrier at its end.
+    constexpr bool use_dma = !PRO;                             // PRO: the fused BatchNorm + LeakyReLU prologue needs the register path
+    auto dma = [&](int c, int buf) {
+        char* hs = Hs(buf);
+        char* ws = Ws(buf);
+#pragma unroll
+        for (int u = 0; u < HPIECES; ++u) {
+            const int p = tid + HTHREADS * u;
+            if (p < HROWS * 2) {
+                const void* src = hsrc[u] >= 0 ? (const void*)(x + hsrc[u] + 16 * c) : (const void*)g_halo_zero;
+                glds16(src, hs + (size_t)(p - lane) * 16);
+            }
+        }
+        const bf16_t* wsrc = wh + (long)c * (WBYTES / 2);
+#pragma unroll
+        for (int u = 0; u < WPIECES; ++u) {
+            const int p = tid + HTHREADS * u;
+            if (p < WBYTES / 16) {
+                const int row = p >> 2, ch = (p & 3) ^ ((0 - (row >> 2)) & 3);
+                glds16(wsrc + 8 * (row * 4 + ch), ws + (size_t)(p - lane) * 16);
+            }
+        }
+    };
+
     // ---- this wave's TPW voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
     constexpr int WPR = HB_W / TPW;                               // waves per brick row
     const int th = wave / WPR, tw0 = (wave % WPR) * TPW;
@@ -169,12 +206,17 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
 #pragma unroll
         for (int nt = 0; nt < NTN; ++nt) acc[i][nt] = fzero4();
 
-    fetch(0);
-    stage(0);
+    if (use_dma) {
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        fetch(0);
+        stage(0);
+    }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) fetch(c + 1);
+        if (c + 1 < nchunks) { if (use_dma) dma(c + 1, buf ^ 1); else fetch(c + 1); }
         const char* hs = Hs(buf);
         const char* ws = Ws(buf) + wbyte;
         // fragments of k-step j+1 are read while the MFMAs of k-step j run (two register sets, loop fully unrolled)
@@ -199,7 +241,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
             // late in this chunk: the global loads issued at the top have landed by then and the writes overlap the
             // remaining MFMAs.  (Spreading the pieces over k-steps 2..12 instead measured 4-20 % SLOWER: the early
             // writes wait for their loads and an in-order wave stalls its MFMAs behind them.)
-            if (j == KSTEPS - 4 && c + 1 < nchunks) stage(buf ^ 1);
+            if (j == KSTEPS - 4 && c + 1 < nchunks && !use_dma) stage(buf ^ 1);
             // Without the fences the machine scheduler sinks every ds_read to just above its first use (read, wait, MFMA):
             // with two waves per SIMD nothing hides the LDS latency then and the matrix pipe sat at 37 % busy.
             __builtin_amdgcn_sched_barrier(0);
@@ -209,6 +251,9 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
                 for (int i = 0; i < TPW; ++i) acc[i][nt] = mfma16(wf[cur][nt], vf[cur][i], acc[i][nt]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the DMAs into the other buffer are ordered for the next chunk's ds_reads only by every issuing wave's vmcnt
+        // wait followed by the barrier
+        if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -319,7 +364,7 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     hipStream_t st = (hipStream_t)stream;
 #define HALO_LAUNCH(N, W)                                                                                                \
     do {                                                                                                                 \
-        auto kern = k_conv3d_halo<N, W>;                                                                                 \
+        auto kern = d->pro_affine ? k_conv3d_halo<N, W, true> : k_conv3d_halo<N, W, false>;                             \
         MIVP_LDS_OPT_IN(kern, lds);                                                                                      \
         hipLaunchKernelGGL(kern, dim3((unsigned)bricks, (unsigned)groups), dim3(BrickOf<W>::G::THREADS), lds, st, *d,    \
                            (const bf16_t*)x, (const bf16_t*)wh, bias, scale, shift, (const bf16_t*)residual, (bf16_t*)y); \
