@@ -477,15 +477,19 @@ namespace {
 __global__ __launch_bounds__(256) void k_uphead_fold(const float* __restrict__ w, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int cout, int cin, int mp,
                                                      bf16_t* __restrict__ wf) {
-    for (int e = threadIdx.x; e < mp * 64; e += 256) {
-        const int row = e >> 6, col = e & 63;
-        float v = 0.f;
-        if (row < 27 * cout) {
+    // one wave per row, lane = column: every load of a row is independent, the shift column is a wave reduction
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < mp; row += 4 * gridDim.x) {
+        float v = 0.f, part = 0.f;
+        if (row < 27 * cout && lane < cin) {
             const int tap = row / cout, co = row - tap * cout;
-            if (col < cin) v = w[((long)co * cin + col) * 27 + tap] * scale[col];
-            else if (col == cin) { for (int c = 0; c < cin; ++c) v += w[((long)co * cin + c) * 27 + tap] * shift[c]; }
+            const float wv = w[((long)co * cin + lane) * 27 + tap];
+            v = wv * scale[lane];
+            part = wv * shift[lane];
         }
-        wf[e] = (bf16_t)v;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == cin) v = part;
+        wf[row * 64 + lane] = (bf16_t)v;
     }
 }
 
@@ -522,7 +526,7 @@ extern "C" int mivp_uphead_fold(const float* conv_w, const float* scale, const f
     MIVP_REQUIRE(conv_w && scale && shift && wf);
     MIVP_REQUIRE(Cout >= 1 && Cin >= 1 && Cin < 64);
     const int mp = (27 * Cout + 15) / 16 * 16;
-    hipLaunchKernelGGL(k_uphead_fold, dim3(1), dim3(256), 0, (hipStream_t)stream, conv_w, scale, shift, Cout, Cin, mp, (bf16_t*)wf);
+    hipLaunchKernelGGL(k_uphead_fold, dim3((mp + 3) / 4), dim3(256), 0, (hipStream_t)stream, conv_w, scale, shift, Cout, Cin, mp, (bf16_t*)wf);
     return mivp_check_launch("uphead_fold");
 }
 
