@@ -399,19 +399,29 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
                         dp[2] = drop_keep(h1, 0, d.attn_drop_thr) ? dp[2] * d.attn_drop_scale : 0.f;
                         dp[3] = drop_keep(h1, 1, d.attn_drop_thr) ? dp[3] * d.attn_drop_scale : 0.f;
                     }
-                    if (!(MASKED && cut)) {
-                        // no shift mask in effect; padding keys are already at P = 0 through their bias (common.hpp)
+                    const int key_lo = 16 * (t0 + lt);
+                    if (!(MASKED && cut) || key_lo >= d.Nq) {
+                        // no shift mask in effect (or a tile of prompt / padding keys only, which is never masked); padding
+                        // keys are already at P = 0 through their bias (common.hpp)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ds[hh][j] = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
                     } else {
+                        // a masked logit is the constant 0: it keeps its share of the softmax but carries no gradient
                         const int4 kr4 = *reinterpret_cast<const int4*>(ridk + 16 * lt + 4 * g);
                         const int krs[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+                        if (key_lo + 16 <= d.Nq) {                       // content keys only: one compare per element
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // a masked logit is the constant 0: it keeps its share of the softmax but carries no gradient
-                            const bool live = (krs[j] == rqi) | (krs[j] == -2);
-                            const float val = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
-                            ds[hh][j] = live ? val : 0.f;
+                            for (int j = 0; j < 4; ++j) {
+                                const float val = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
+                                ds[hh][j] = krs[j] == rqi ? val : 0.f;
+                            }
+                        } else {                                         // the one tile that mixes content and padding keys
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool live = (krs[j] == rqi) | (krs[j] == -2);
+                                const float val = __builtin_amdgcn_exp2f(s[j]) * (dp[j] - dli);
+                                ds[hh][j] = live ? val : 0.f;
+                            }
                         }
                     }
                 }
@@ -608,6 +618,13 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
 #pragma unroll
                     for (int s = 0; s < DVS; ++s) vf[s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
                 }
+                // A key tile made of prompt / padding keys only is never masked: it takes the lean path even in a cut window.
+                // Elsewhere "live" = (key class == query region) | (prompt or padding key) is ONE compare on pre-or-ed
+                // operands -- (rq | pm) == kk with pm = all ones and kk = all ones for prompt / padding lanes -- so that no
+                // scalar mask arithmetic (and none of its VALU->SALU->VALU hazard stalls) sits in the per-element stream.
+                const uint32_t pm = kcls == -2 ? 0xFFFFFFFFu : 0u, kk = kcls == -2 ? 0xFFFFFFFFu : (uint32_t)kcls;
+                auto uloop = [&](auto masked_c) {
+                constexpr bool MSK = decltype(masked_c)::value;
                 for (int u = 0; u < ntc / 2; ++u) {
                     f32x4 pv[2], ds[2];
 #pragma unroll
@@ -638,9 +655,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                                 keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                             }
                             float p, dsv;
-                            if (CUT) {
+                            if (MSK) {
                                 // a masked logit is the constant 0 (accumulator value ls[j]): it keeps its P, carries no gradient
-                                const bool live = (kcls == rqs[j]) | (kcls == -2);
+                                const bool live = ((uint32_t)rqs[j] | pm) == kk;
                                 p = __builtin_amdgcn_exp2f(live ? s[j] : ls[j]);
                                 dsv = live ? p * (dp[j] * keep - dls[j]) : 0.f;
                             } else {
@@ -685,6 +702,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void 
                         }
                     }
                 }
+                };
+                if (CUT && kt * 16 < d.Nq) uloop(std::true_type{});
+                else uloop(std::false_type{});
             }
         };
         if (MASKED && cut) compute(std::true_type{});
