@@ -78,7 +78,14 @@ def lib():
     return _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The current HIP stream of the current device as a C pointer (every kernel is launched on it).  The raw getter is
+    ~10x cheaper than building a torch.cuda.Stream object per launch (80+ launches per step)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
