@@ -1,10 +1,12 @@
 """Diagnostic (not a test): per-parameter gradient error of the HIP path vs the oracle, with two
 conditioning yardsticks (how far the oracle's / the HIP path's own gradient moves under bf16-level
-input noise).  usage: python tools/grad_report.py TAG [SIZE]"""
+input noise).  usage: python tests/aux/grad_report.py TAG [SIZE]"""
 import sys
 from argparse import Namespace
 import torch
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import os
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from conftest import load_fixture, rel_l2
 from test_hip_model import round_weights
 import mivp_amd

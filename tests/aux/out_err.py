@@ -1,7 +1,8 @@
 """Forward error of the product model against the oracle on the toy fixtures (prints rel-L2 per output)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))           # tests/ (conftest, test_hip_model)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))     # repository root
 from argparse import Namespace
 import torch
 from conftest import load_fixture, rel_l2

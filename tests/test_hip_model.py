@@ -12,7 +12,7 @@ within 3e-2 of the golden output captured from the reference with un-rounded wei
 Gradients: every block's backward is checked tightly in isolation (test_hip_swin_bwd.py, 1.5e-2).
 End to end the randomly initialised toy network is ill-conditioned: perturbing the INPUT by bf16-level
 relative noise (2^-9) moves the fp32 oracle's own prompt gradients by 3-12 % and the HIP path's by
-up to 26 % (tools/grad_report.py prints both).  So each trained parameter's gradient must (a) point the
+up to 26 % (tests/aux/grad_report.py prints both).  So each trained parameter's gradient must (a) point the
 same way, cosine > 0.9, and (b) sit within max(5e-2, 3 x yardstick) rel-L2 of the oracle's, the
 yardstick being the larger of those two self-sensitivities for that parameter."""
 from argparse import Namespace
@@ -145,7 +145,7 @@ def _check_all_gradients(conf, sd, x, gouts, trainable, out_tol):
     model_p, out_p = product_run(xp)
     for k, v in want.items():
         # the bf16 path's own sensitivity to rounding-level input noise bounds what a comparison can resolve: on the 16^3
-        # toy fixtures with prompts two HIP runs whose inputs differ by 2^-9 relative noise are 3e-2 apart (tools/out_err.py)
+        # toy fixtures with prompts two HIP runs whose inputs differ by 2^-9 relative noise are 3e-2 apart (tests/aux/out_err.py)
         self_noise = rel_l2(out_p[k].float().cpu(), out[k].float().cpu())
         assert rel_l2(out[k].float().cpu(), v.detach()) < max(out_tol, 1.25 * self_noise), (k, self_noise)
     params = dict(model.named_parameters())

@@ -6,7 +6,7 @@ import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mivp_amd
 from mivp_amd import swin_ops
-from oracle.unetr_ref import _block_state
+from mivp_amd.swin_unetr import SwinTransformerBlock
 
 STAGES = {  # C, heads, dims (96^3 input), prompts
     "enc0": (48, 4, (48, 48, 48), 64), "enc1": (96, 8, (24, 24, 24), 64), "enc2": (192, 16, (12, 12, 24), 64),
@@ -18,8 +18,8 @@ shift = (3, 3, 3) if (len(sys.argv) > 3 and sys.argv[3] == "shift") else (0, 0, 
 C, heads, dims, npr = STAGES[stage]
 B, window = 4, (7, 7, 7)
 gen = torch.Generator().manual_seed(0)
-sd = {}
-_block_state(sd, "", C, heads, list(window), 64, max(npr, 1), npr > 0, gen)
+torch.manual_seed(0)
+sd = SwinTransformerBlock(C, window, 64, heads, 1, max(npr, 1), use_token_params=npr > 0).state_dict()   # random init
 dev = torch.device("cuda")
 w = swin_ops.weights_from_state(sd, "", heads, 64, npr, dev, need_bwd=True)
 x = torch.randn(B, *dims, C, generator=gen).to(dev, torch.bfloat16)
