@@ -396,6 +396,140 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint(const float* __restrict_
     for (int c = 27 * COUT; c < ldD; ++c) dst[c] = (bf16_t)0.0f;
 }
 
+// Cout == 2, contiguous dy: the same adjoint with the dy neighbourhoods served from LDS.  A workgroup owns a brick of
+// 4 x 4 x 16 low-res cells (one thread each) and stages the 12 x 12 x 36 high-res voxels they touch ONCE (10 16-byte
+// loads per thread instead of 108 overlapping ones per cell: the plain kernel is bound by its load instruction count).
+constexpr int AB_H = 4, AB_W = 4, AB_D = 16;
+constexpr int AV_H = 2 * AB_H + 4, AV_W = 2 * AB_W + 4, AV_D = 2 * AB_D + 4;     // staged high-res voxels per axis
+__global__ __launch_bounds__(256) void k_uphead_adjoint_brick(const float* __restrict__ dy, int B, int h, int w, int d,
+                                                              bf16_t* __restrict__ D, int ldD) {
+    constexpr int COUT = 2;
+    __shared__ __attribute__((aligned(16))) float sdy[AV_H * AV_W * AV_D * 2];
+    const int nbd = (d + AB_D - 1) / AB_D, nbw = (w + AB_W - 1) / AB_W, nbh = (h + AB_H - 1) / AB_H;
+    int brick = blockIdx.x;
+    const int bd = brick % nbd; brick /= nbd;
+    const int bw = brick % nbw; brick /= nbw;
+    const int bh = brick % nbh;
+    const long b = brick / nbh;
+    const int OH = 2 * h, OW = 2 * w, OD = 2 * d;
+    const int o0 = 2 * bh * AB_H - 2, o1 = 2 * bw * AB_W - 2, o2 = 2 * bd * AB_D - 2;     // brick origin in high-res voxels (even)
+    for (int e = threadIdx.x; e < AV_H * AV_W * (AV_D / 2); e += 256) {                   // voxel pairs along d
+        const int pr = e % (AV_D / 2), v1 = (e / (AV_D / 2)) % AV_W, v0 = e / ((AV_D / 2) * AV_W);
+        const int u0 = o0 + v0, u1 = o1 + v1, u2 = o2 + 2 * pr;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)u0 < (unsigned)OH && (unsigned)u1 < (unsigned)OW && (unsigned)u2 < (unsigned)OD)
+            val = *reinterpret_cast<const float4*>(dy + ((((b * OH + u0) * OW + u1) * (long)OD) + u2) * 2);
+        *reinterpret_cast<float4*>(sdy + ((v0 * AV_W + v1) * AV_D + 2 * pr) * 2) = val;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int l2 = t % AB_D, l1 = (t / AB_D) % AB_W, l0 = t / (AB_D * AB_W);
+    const int q0 = bh * AB_H + l0, q1 = bw * AB_W + l1, q2 = bd * AB_D + l2;
+    const bool inside = q0 < h && q1 < w && q2 < d;
+    float c0[4], c1[4], c2[4];
+    axis_coef(inside ? q0 : 0, h, c0);
+    axis_coef(inside ? q1 : 0, w, c1);
+    axis_coef(inside ? q2 : 0, d, c2);
+    float acc[3][3][3][COUT];
+#pragma unroll
+    for (int k0 = 0; k0 < 3; ++k0)
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] = 0.f;
+    if (inside) {
+#pragma unroll 1
+    for (int v0 = 0; v0 < 6; ++v0) {
+        float F[3][3][COUT];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) F[k1][k2][co] = 0.f;
+#pragma unroll
+        for (int v1 = 0; v1 < 6; ++v1) {
+            // cell-local voxel (v0, v1, .) = staged voxel (2 l0 + v0, 2 l1 + v1, 2 l2 + .); outside the volume: staged zeros
+            const float* row = sdy + (((2 * l0 + v0) * AV_W + (2 * l1 + v1)) * AV_D + 2 * l2) * 2;
+            float rv[6][COUT];
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * pr);
+                rv[2 * pr][0] = v.x; rv[2 * pr][1] = v.y; rv[2 * pr + 1][0] = v.z; rv[2 * pr + 1][1] = v.w;
+            }
+            float E[3][COUT];
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e += c2[j] * rv[j + 2 - k2][co];
+                    E[k2][co] = e;
+                }
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1) {
+                const int j1 = v1 - 2 + k1;
+                if (j1 < 0 || j1 > 3) continue;
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) F[k1][k2][co] += c1[j1] * E[k2][co];
+            }
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < 3; ++k0) {
+            const int j0 = v0 - 2 + k0;
+            const float cw = j0 == 0 ? c0[0] : (j0 == 1 ? c0[1] : (j0 == 2 ? c0[2] : (j0 == 3 ? c0[3] : 0.f)));
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[k0][k1][k2][co] += cw * F[k1][k2][co];
+        }
+    }
+    }
+    // rows leave through LDS: a thread's own 128-byte row would be written as eight 16-byte stores at a 128-byte lane
+    // stride (64 partial lines per instruction); staged (row stride 144 B: no bank conflicts), a wave writes whole rows
+    __syncthreads();                                          // every wave is done reading the dy brick
+    constexpr int RSTRIDE = 144;
+    char* srow = reinterpret_cast<char*>(sdy);
+    if (inside) {
+        bf16_t vals[64];
+#pragma unroll
+        for (int k0 = 0; k0 < 3; ++k0)
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) vals[((k0 * 3 + k1) * 3 + k2) * COUT + co] = (bf16_t)acc[k0][k1][k2][co];
+#pragma unroll
+        for (int c = 27 * COUT; c < 64; ++c) vals[c] = (bf16_t)0.0f;
+#pragma unroll
+        for (int sgm = 0; sgm < 8; ++sgm) {
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = vals[8 * sgm + i];
+            *reinterpret_cast<bf16x8*>(srow + t * RSTRIDE + 16 * sgm) = v;
+        }
+    }
+    __syncthreads();
+    const int segs = ldD / 8;                                 // 16-byte pieces per D row (ldD <= 64)
+    for (int e = t; e < 256 * segs; e += 256) {
+        const int row = e / segs, sgm = e - row * segs;
+        const int r2 = row % AB_D, r1 = (row / AB_D) % AB_W, r0 = row / (AB_D * AB_W);
+        const int g0 = bh * AB_H + r0, g1 = bw * AB_W + r1, g2 = bd * AB_D + r2;
+        if (g0 < h && g1 < w && g2 < d) {
+            const long pcell = ((b * h + g0) * w + g1) * (long)d + g2;
+            st8(D + pcell * ldD + 8 * sgm, *reinterpret_cast<const bf16x8*>(srow + row * RSTRIDE + 16 * sgm));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // gradient w.r.t. the low-resolution input.  With z = scale*Ux + shift, dz = conv^T dy, the training-mode BatchNorm
 // backward is dUx = scale * (dz - S1/N - xhat * S2/N) (S1 = sum dz = dbeta, S2 = sum dz*xhat = dgamma, xhat = (Ux - mu) rstd)
@@ -593,6 +727,11 @@ extern "C" int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B
     const long T = (long)B * h * w * d;
     const unsigned grid = (unsigned)((T + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    if (Cout == 2 && dy_stride == 2 && ldD <= 64) {          // LDS-staged brick form (the downstream head's case)
+        const unsigned bricks = (unsigned)((long)B * ((h + AB_H - 1) / AB_H) * ((w + AB_W - 1) / AB_W) * ((d + AB_D - 1) / AB_D));
+        hipLaunchKernelGGL(k_uphead_adjoint_brick, dim3(bricks), dim3(256), 0, st, dy, (int)B, (int)h, (int)w, (int)d, (bf16_t*)D, (int)ldD);
+        return mivp_check_launch("uphead_adjoint");
+    }
 #define UP_ADJ(CO) hipLaunchKernelGGL((k_uphead_adjoint<CO>), dim3(grid), dim3(256), 0, st, dy, (int)dy_stride, (int)B, (int)h, (int)w, \
                                       (int)d, (bf16_t*)D, (int)ldD)
     switch (Cout) {
