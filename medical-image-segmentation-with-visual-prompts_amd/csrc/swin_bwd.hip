@@ -862,62 +862,89 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
 // ---------------------------------------------------------------------------------------------
 // prompt K/V backward: (dKp, dVp) -> to_k / to_v -> LayerNorm backward -> dprompt   (64 rows: VALU)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prompt_kv_bwd(MivpSwinDesc d, const float* __restrict__ dkp,
-                                                       const float* __restrict__ dvp, const float* __restrict__ prompt,
-                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                       const bf16_t* __restrict__ wqkv, float* __restrict__ dprompt,
-                                                       bf16_t* __restrict__ wg_a, bf16_t* __restrict__ wg_n,
-                                                       float* __restrict__ wg_ln) {
+__global__ __launch_bounds__(1024) void k_prompt_kv_bwd(MivpSwinDesc d, const float* __restrict__ dkp,
+                                                        const float* __restrict__ dvp, const float* __restrict__ prompt,
+                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        const bf16_t* __restrict__ wqkv, float* __restrict__ dprompt,
+                                                        bf16_t* __restrict__ wg_a, bf16_t* __restrict__ wg_n,
+                                                        float* __restrict__ wg_ln) {
     // weight-gradient mode (all three or none): wg_a [2][Np][C] bf16 = dK rows, dV rows (head-merged), wg_n [Np][C] bf16 =
     // LN(prompt) (the to_k / to_v input), wg_ln [2][Np][C] f32 = per-row dbeta terms, dgamma terms of attn_norm
+    // One workgroup (16 waves) per prompt row.  The two C x C mat-vecs are the cost: lane = channel, the 16 waves split
+    // the contraction index and their partial sums meet in LDS in wave order (the single-wave-per-channel form was a
+    // 2C-long serial chain per thread: 28 us per launch, twelve launches per step with prompts on both sides).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gk = reinterpret_cast<float*>(smem);            // [C] dK row (head-merged)
     float* gv = gk + d.C;                                    // [C]
-    float* red = gv + d.C;                                   // [16]
+    float* dy = gv + d.C;                                    // [C] gradient w.r.t. the LayerNorm output
+    float* red = dy + d.C;                                   // [16]
+    float* accs = red + 16;                                  // [16][64]
     const int t = blockIdx.x, C = d.C, hd = C / d.heads, tid = threadIdx.x;
-    for (int n = tid; n < C; n += 256) {
+    for (int n = tid; n < C; n += 1024) {
         const int head = n / hd, j = n - head * hd;
         gk[n] = dkp[((long)head * d.Npp + t) * hd + j];
         gv[n] = dvp[((long)head * d.Npp + t) * hd + j];
     }
-    // LayerNorm statistics of the prompt row
+    // LayerNorm statistics of the prompt row (waves 0-3)
     float part = 0.f;
-    for (int c = tid; c < C; c += 256) part += prompt[(long)t * C + c];
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
+    if (tid < 256) {
+        for (int c = tid; c < C; c += 256) part += prompt[(long)t * C + c];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+    }
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
-    part = 0.f;
-    for (int c = tid; c < C; c += 256) { const float dvv = prompt[(long)t * C + c] - mean; part += dvv * dvv; }
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = part;
+    if (tid < 256) {
+        part = 0.f;
+        for (int c = tid; c < C; c += 256) { const float dvv = prompt[(long)t * C + c] - mean; part += dvv * dvv; }
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = part;
+    }
     __syncthreads();
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + d.ln_eps);
-    // dy[c] = sum_n gk[n] Wk[n][c] + gv[n] Wv[n][c] ; then LN backward (each thread owns channels c, c+256, ...)
+    // dy[c] = sum_n gk[n] Wk[n][c] + gv[n] Wv[n][c]
+    const int cl = tid & 63, slice = tid >> 6;
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c = cb + cl;
+        float acc = 0.f;
+        if (c < C)
+            for (int n = slice; n < C; n += 16)
+                acc += gk[n] * (float)wqkv[(long)(C + n) * C + c] + gv[n] * (float)wqkv[(long)(2 * C + n) * C + c];
+        accs[slice * 64 + cl] = acc;
+        __syncthreads();
+        if (slice == 0 && c < C) {
+            float tot = 0.f;
+            for (int k = 0; k < 16; ++k) tot += accs[k * 64 + cl];
+            dy[c] = tot;
+        }
+        __syncthreads();
+    }
+    // LayerNorm backward (waves 0-3; each thread owns channels c, c+256, ...)
     float s1 = 0.f, s2 = 0.f;
     float dxh_loc[4], xh_loc[4];
     int cnt = 0;
-    for (int c = tid; c < C; c += 256, ++cnt) {
-        float acc = 0.f;
-        for (int n = 0; n < C; ++n)
-            acc += gk[n] * (float)wqkv[(long)(C + n) * C + c] + gv[n] * (float)wqkv[(long)(2 * C + n) * C + c];
-        const float dxh = acc * ln_w[c];
-        const float xh = (prompt[(long)t * C + c] - mean) * rstd;
-        if (wg_a) {
-            wg_a[(long)t * C + c] = (bf16_t)gk[c];
-            wg_a[((long)d.Np + t) * C + c] = (bf16_t)gv[c];
-            wg_n[(long)t * C + c] = (bf16_t)(xh * ln_w[c] + ln_b[c]);
-            wg_ln[(long)t * C + c] = acc;
-            wg_ln[((long)d.Np + t) * C + c] = acc * xh;
+    if (tid < 256) {
+        for (int c = tid; c < C; c += 256, ++cnt) {
+            const float acc = dy[c];
+            const float dxh = acc * ln_w[c];
+            const float xh = (prompt[(long)t * C + c] - mean) * rstd;
+            if (wg_a) {
+                wg_a[(long)t * C + c] = (bf16_t)gk[c];
+                wg_a[((long)d.Np + t) * C + c] = (bf16_t)gv[c];
+                wg_n[(long)t * C + c] = (bf16_t)(xh * ln_w[c] + ln_b[c]);
+                wg_ln[(long)t * C + c] = acc;
+                wg_ln[((long)d.Np + t) * C + c] = acc * xh;
+            }
+            dxh_loc[cnt] = dxh;
+            xh_loc[cnt] = xh;
+            s1 += dxh;
+            s2 += dxh * xh;
         }
-        dxh_loc[cnt] = dxh;
-        xh_loc[cnt] = xh;
-        s1 += dxh;
-        s2 += dxh * xh;
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((tid & 63) == 0) { red[8 + (tid >> 6)] = s1; red[12 + (tid >> 6)] = s2; }
     }
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((tid & 63) == 0) { red[8 + (tid >> 6)] = s1; red[12 + (tid >> 6)] = s2; }
     __syncthreads();
+    if (tid >= 256) return;
     const float m1 = (red[8] + red[9] + red[10] + red[11]) / (float)C;
     const float m2 = (red[12] + red[13] + red[14] + red[15]) / (float)C;
     cnt = 0;
@@ -1113,7 +1140,7 @@ extern "C" int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const
     MIVP_REQUIRE(d->Np > 0 && dkp && dvp && prompt && ln_w && ln_b && wqkv && dprompt);
     MIVP_REQUIRE((wg_a == nullptr) == (wg_n == nullptr) && (wg_a == nullptr) == (wg_ln == nullptr));
     MIVP_REQUIRE(d->C <= 1024);
-    hipLaunchKernelGGL(k_prompt_kv_bwd, dim3(d->Np), dim3(256), (2 * d->C + 16) * sizeof(float), (hipStream_t)stream, *d,
+    hipLaunchKernelGGL(k_prompt_kv_bwd, dim3(d->Np), dim3(1024), (3 * d->C + 16 + 16 * 64) * sizeof(float), (hipStream_t)stream, *d,
                        dkp, dvp, prompt, ln_w, ln_b, (const bf16_t*)wqkv, dprompt, (bf16_t*)wg_a, (bf16_t*)wg_n, wg_ln);
     return mivp_check_launch("prompt_kv_bwd");
 }
