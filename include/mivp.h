@@ -175,6 +175,11 @@ int mivp_dropout_masks(const MivpSwinDesc* d, uint8_t* attn_keep, uint8_t* proj_
 
 /* out[r] = sum_i in[i][r]  for i < n, r < rows  (deterministic two-level tree) */
 int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream);
+/* the same for up to four arrays that share n (the prompt-gradient partials of one block), one launch:
+ * out[i][r] = sum_k in[i][k*rows[i] + r];  in / rows / out are HOST arrays of nseg entries */
+int mivp_reduce_rows_multi(int32_t nseg, const float* const* in, const int64_t* rows, float* const* out, int64_t n,
+                           mivp_stream_t stream);
+
 
 /* ------------------------------------------------------------------------ */
 /* Patch merging (swin_transformer/down.py:21-53)                           */

@@ -80,6 +80,57 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ 
     if (slice == 0 && rr < rows) out[rr] = part[0][col];
 }
 
+// several [n][rows_i] partial arrays in one launch (the prompt-gradient partials of one block: dKp, dVp, token scores)
+struct ReduceSegs {
+    const float* in[4];
+    float* out[4];
+    long rows[4];
+    int first_block[5];                                       // block range of segment i = [first_block[i], first_block[i+1])
+};
+__global__ __launch_bounds__(1024) void k_reduce_rows_multi(ReduceSegs sg, int nseg, long n) {
+    __shared__ float part[32][33];
+    int seg = 0;
+    while (seg + 1 < nseg && (int)blockIdx.x >= sg.first_block[seg + 1]) ++seg;
+    const float* __restrict__ in = sg.in[seg];
+    const long rows = sg.rows[seg];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const long rr = (long)(blockIdx.x - sg.first_block[seg]) * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (rr < rows) {
+        long i = slice;
+        for (; i + 32 < n; i += 64) { a0 += in[i * rows + rr]; a1 += in[(i + 32) * rows + rr]; }
+        if (i < n) a0 += in[i * rows + rr];
+    }
+    part[slice][col] = a0 + a1;
+    __syncthreads();
+    for (int h = 16; h > 0; h >>= 1) {
+        if (slice < h) part[slice][col] += part[slice + h][col];
+        __syncthreads();
+    }
+    if (slice == 0 && rr < rows) sg.out[seg][rr] = part[0][col];
+}
+
+extern "C" int mivp_reduce_rows_multi(int32_t nseg, const float* const* in, const int64_t* rows, float* const* out, int64_t n,
+                                      mivp_stream_t stream) {
+    MIVP_REQUIRE(nseg >= 1 && nseg <= 4 && in && rows && out && n >= 0);
+    ReduceSegs sg;
+    int blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        sg.first_block[i] = blocks;
+        if (i < nseg) {
+            MIVP_REQUIRE(in[i] && out[i] && rows[i] > 0);
+            sg.in[i] = in[i]; sg.out[i] = out[i]; sg.rows[i] = (long)rows[i];
+            blocks += (int)((rows[i] + 31) / 32);
+        } else {
+            sg.in[i] = nullptr; sg.out[i] = nullptr; sg.rows[i] = 0;
+        }
+    }
+    sg.first_block[4] = blocks;
+    for (int i = nseg; i < 4; ++i) sg.first_block[i + 1] = blocks;
+    hipLaunchKernelGGL(k_reduce_rows_multi, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, sg, (int)nseg, (long)n);
+    return mivp_check_launch("reduce_rows_multi");
+}
+
 extern "C" int mivp_reduce_rows(const float* in, int64_t n, int64_t rows, float* out, mivp_stream_t stream) {
     MIVP_REQUIRE(in && out && n >= 0 && rows > 0);
     hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((rows + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, in, (long)n,

@@ -294,9 +294,10 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
         dkp = torch.empty((heads, d.Npp, hd), dtype=torch.float32, device=dev)
         dvp = torch.empty_like(dkp)
         dtok = torch.empty((heads, d.Npp), dtype=torch.float32, device=dev)
-        L.call("mivp_reduce_rows", L.ptr(dkp_part), C.c_int64(BP), C.c_int64(rows), L.ptr(dkp), st)
-        L.call("mivp_reduce_rows", L.ptr(dvp_part), C.c_int64(BP), C.c_int64(rows), L.ptr(dvp), st)
-        L.call("mivp_reduce_rows", L.ptr(dtok_part), C.c_int64(BP), C.c_int64(heads * d.Npp), L.ptr(dtok), st)
+        ins = (C.c_void_p * 3)(dkp_part.data_ptr(), dvp_part.data_ptr(), dtok_part.data_ptr())
+        outs = (C.c_void_p * 3)(dkp.data_ptr(), dvp.data_ptr(), dtok.data_ptr())
+        nrows = (C.c_int64 * 3)(rows, rows, heads * d.Npp)
+        L.call("mivp_reduce_rows_multi", C.c_int32(3), ins, nrows, outs, C.c_int64(BP), st)     # one launch for the three
         pr = prompt.detach().to(torch.float32).contiguous()
         dprompt = torch.empty_like(pr)
         wg_a = wg_n = wg_ln = None
