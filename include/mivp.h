@@ -91,6 +91,14 @@ int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_s
 int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* ln_w, const float* ln_b,
                        const void* wqkv, void* kp, void* vp, float* yln, mivp_stream_t stream);
 
+/* prompt-token bias scores and their gradients (relative_positional_encoding.py:128-135):
+ *   ts[h][t] = scale * sum_k W[h][k] * E[t][k]   (W = weights_token [heads][e], E = enc_token rows [Np][e], all f32)
+ *   dW[h][k] = scale * sum_t dts[h][t] E[t][k],  dE[t][k] = scale * sum_h dts[h][t] W[h][k]                       */
+int mivp_token_scores_fwd(const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale, float* ts,
+                          mivp_stream_t stream);
+int mivp_token_scores_bwd(const float* dts, const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale,
+                          float* dW, float* dE, mivp_stream_t stream);
+
 /* relative-position bias as MFMA augmentation dims (relative_positional_encoding.py:99-142)
  *   t_h [heads][2*w0-1], t_w, t_d: per-axis relative tables  T_a[h][j-i+w_a-1] = s/3 * W_a[h] . E_a[...]
  *   (scale embed_dim**-0.5 and the /3 already applied by the host), ts [heads][Np] f32 prompt-token

@@ -80,6 +80,66 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ 
     if (slice == 0 && rr < rows) out[rr] = part[0][col];
 }
 
+// prompt-token bias scores (relative_positional_encoding.py:128-135): ts[h][t] = scale * <W[h], E[t]> and its gradients.
+// heads <= 64, Np <= 64 tokens, embed dim e: one workgroup (the torch form was ~8 tiny launches per prompted block and step)
+// operands are staged in LDS first: a thread walking global memory through a 64-long dependent chain costs ~50 us
+__global__ __launch_bounds__(256) void k_token_scores_fwd(const float* __restrict__ W, const float* __restrict__ E, int heads,
+                                                          int np, int e, float scale, float* __restrict__ ts) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+    float* Ws = reinterpret_cast<float*>(smem_ts);             // [heads][e + 1]
+    float* Es = Ws + heads * (e + 1);                          // [np][e + 1]
+    for (int i = threadIdx.x; i < heads * e; i += 256) Ws[(i / e) * (e + 1) + i % e] = W[i];
+    for (int i = threadIdx.x; i < np * e; i += 256) Es[(i / e) * (e + 1) + i % e] = E[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * np; i += 256) {
+        const int h = i / np, t = i - h * np;
+        float acc = 0.f;
+        for (int k = 0; k < e; ++k) acc += Ws[h * (e + 1) + k] * Es[t * (e + 1) + k];
+        ts[i] = acc * scale;
+    }
+}
+__global__ __launch_bounds__(256) void k_token_scores_bwd(const float* __restrict__ dts, const float* __restrict__ W,
+                                                          const float* __restrict__ E, int heads, int np, int e, float scale,
+                                                          float* __restrict__ dW, float* __restrict__ dE) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+    float* Ws = reinterpret_cast<float*>(smem_ts);             // [heads][e]
+    float* Es = Ws + heads * e;                                // [np][e]
+    float* Ds = Es + np * e;                                   // [heads][np]
+    for (int i = threadIdx.x; i < heads * e; i += 256) Ws[i] = W[i];
+    for (int i = threadIdx.x; i < np * e; i += 256) Es[i] = E[i];
+    for (int i = threadIdx.x; i < heads * np; i += 256) Ds[i] = dts[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * e; i += 256) {       // dW[h][k] = scale * sum_t dts[h][t] E[t][k]
+        const int h = i / e, k = i - h * e;
+        float acc = 0.f;
+        for (int t = 0; t < np; ++t) acc += Ds[h * np + t] * Es[t * e + k];
+        dW[i] = acc * scale;
+    }
+    for (int i = threadIdx.x; i < np * e; i += 256) {          // dE[t][k] = scale * sum_h dts[h][t] W[h][k]
+        const int t = i / e, k = i - t * e;
+        float acc = 0.f;
+        for (int h = 0; h < heads; ++h) acc += Ds[h * np + t] * Ws[h * e + k];
+        dE[i] = acc * scale;
+    }
+}
+
+extern "C" int mivp_token_scores_fwd(const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale, float* ts,
+                                     mivp_stream_t stream) {
+    MIVP_REQUIRE(W && E && ts && heads > 0 && np > 0 && e > 0);
+    const size_t lds = (size_t)(heads + np) * (e + 1) * sizeof(float);
+    MIVP_REQUIRE(lds <= 64 * 1024);
+    hipLaunchKernelGGL(k_token_scores_fwd, dim3(1), dim3(256), lds, (hipStream_t)stream, W, E, heads, np, e, scale, ts);
+    return mivp_check_launch("token_scores_fwd");
+}
+extern "C" int mivp_token_scores_bwd(const float* dts, const float* W, const float* E, int32_t heads, int32_t np, int32_t e,
+                                     float scale, float* dW, float* dE, mivp_stream_t stream) {
+    MIVP_REQUIRE(dts && W && E && dW && dE && heads > 0 && np > 0 && e > 0);
+    const size_t lds = ((size_t)(heads + np) * e + (size_t)heads * np) * sizeof(float);
+    MIVP_REQUIRE(lds <= 64 * 1024);
+    hipLaunchKernelGGL(k_token_scores_bwd, dim3(1), dim3(256), lds, (hipStream_t)stream, dts, W, E, heads, np, e, scale, dW, dE);
+    return mivp_check_launch("token_scores_bwd");
+}
+
 // several [n][rows_i] partial arrays in one launch (the prompt-gradient partials of one block: dKp, dVp, token scores)
 struct ReduceSegs {
     const float* in[4];

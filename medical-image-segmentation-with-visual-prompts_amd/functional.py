@@ -18,6 +18,9 @@ from typing import Optional
 
 import torch
 
+import ctypes as C
+
+from . import _lib as L
 from . import ops, swin_ops
 
 BF16 = torch.bfloat16
@@ -178,6 +181,40 @@ class _SwinBlockTrainFn(torch.autograd.Function):
                 None, None, None, None) + body
 
 
+class _TokenScoresFn(torch.autograd.Function):
+    """ts [heads, Np] = scale * weights_token @ enc_token[:Np].T and both parameter gradients, one tiny kernel each way."""
+
+    @staticmethod
+    def forward(ctx, W, E, n_prompt, scale):
+        Wc, Ec = W.detach().float().contiguous(), E.detach().float().contiguous()
+        heads, e = Wc.shape
+        ts = torch.empty((heads, n_prompt), dtype=torch.float32, device=W.device)
+        L.call("mivp_token_scores_fwd", L.ptr(Wc), L.ptr(Ec), C.c_int32(heads), C.c_int32(n_prompt), C.c_int32(e),
+               C.c_float(scale), L.ptr(ts), L.stream())
+        ctx.save_for_backward(Wc, Ec)
+        ctx.meta = (n_prompt, scale)
+        return ts
+
+    @staticmethod
+    def backward(ctx, dts):
+        Wc, Ec = ctx.saved_tensors
+        n_prompt, scale = ctx.meta
+        heads, e = Wc.shape
+        dW = torch.empty_like(Wc)
+        dE = torch.zeros_like(Ec) if Ec.shape[0] != n_prompt else torch.empty_like(Ec)
+        L.call("mivp_token_scores_bwd", L.ptr(dts.contiguous().float()), L.ptr(Wc), L.ptr(Ec), C.c_int32(heads),
+               C.c_int32(n_prompt), C.c_int32(e), C.c_float(scale), L.ptr(dW), L.ptr(dE), L.stream())
+        return dW, dE, None, None
+
+
+def token_scores(pe, n_prompt):
+    """Bias of the prompt-token key columns (RelativePE.token_scores) through the fused kernels when the block holds
+    one prompt (max_prompts == 1, the reference's configuration); the torch form otherwise."""
+    if len(pe.enc_token) == 1 and pe.enc_token[0].is_cuda and n_prompt <= pe.enc_token[0].shape[0]:
+        return _TokenScoresFn.apply(pe.weights_token, pe.enc_token[0], n_prompt, float(pe.scale))
+    return pe.token_scores(n_prompt)
+
+
 def swin_block(block, x, prompt: Optional[torch.Tensor]):
     pe, attn = block.pe, block.attn
     body = [block.attn_norm.weight, block.attn_norm.bias, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
@@ -197,7 +234,7 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
     if n_prompt:
         if not pe.use_token_params:
             raise RuntimeError("prompt tokens passed to a block built without token bias parameters")
-        ts = pe.token_scores(n_prompt)            # tiny torch matmul: autograd carries d(ts) into the two params
+        ts = token_scores(pe, n_prompt)           # autograd carries d(ts) into weights_token / enc_token
     dropout = None
     p_attn, p_proj = float(attn.attn_drop.p), float(attn.proj_drop.p)
     if block.training and (p_attn > 0 or p_proj > 0):
