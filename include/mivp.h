@@ -382,6 +382,12 @@ int mivp_head_grads(const float* G, int64_t gs_co, int64_t gs_tap, const float* 
                     const float* conv_w, const float* scale, const float* shift, const float* mean_rstd, int32_t Cout,
                     int32_t Cin, float* dW, float* db, float* dgamma, float* dbeta, mivp_stream_t stream);
 
+/* the two small operands of mivp_uphead_dx from the head's parameters and batch statistics (layouts: see mivp_uphead_dx);
+ * n_hr = number of high-resolution voxels 8*B*h*w*d; dgamma / dbeta may be NULL when training == 0 */
+int mivp_uphead_dx_prep(const float* conv_w, const float* scale, const float* mean_rstd, const float* dgamma,
+                        const float* dbeta, double n_hr, int32_t training, int32_t Cout, int32_t Cin, void* wc, float* coef,
+                        mivp_stream_t stream);
+
 /* gradient w.r.t. x [B,h,w,d,C] (bf16) through upsample -> BatchNorm -> conv, all at low resolution:
  *   D with ldD == 64; wc bf16 [16*ceil(C/16)][64] = conv weight as [c][tap*Cout + co] (zero padded);
  *   coef f32 [4][C] = (BN scale | sum(dz)/N | rstd*sum(dz*xhat)/N | batch mean), rows 1-2 zero for eval-mode BN */

@@ -655,6 +655,40 @@ __global__ __launch_bounds__(256) void k_head_grads(const float* __restrict__ G,
 }
 }  // namespace
 
+// operands of k_uphead_dx from the head's parameters and statistics (one workgroup; was ~10 tiny torch launches):
+//   wc bf16 [16*ceil(C/16)][64] = conv weight as [c][tap*Cout + co] (zero padded)
+//   coef f32 [4][C] = (BN scale | dbeta / N | rstd * dgamma / N | batch mean); rows 1-2 zero for eval-mode BatchNorm
+namespace {
+__global__ __launch_bounds__(256) void k_uphead_dx_prep(const float* __restrict__ w, const float* __restrict__ scale,
+                                                        const float* __restrict__ mean_rstd, const float* __restrict__ dgamma,
+                                                        const float* __restrict__ dbeta, float inv_n, int training, int cout,
+                                                        int cin, int cp, bf16_t* __restrict__ wc, float* __restrict__ coef) {
+    for (int e = threadIdx.x; e < cp * 64; e += 256) {
+        const int c = e >> 6, col = e & 63;
+        float v = 0.f;
+        if (c < cin && col < 27 * cout) { const int tap = col / cout, co = col - tap * cout; v = w[((long)co * cin + c) * 27 + tap]; }
+        wc[e] = (bf16_t)v;
+    }
+    for (int c = threadIdx.x; c < cin; c += 256) {
+        coef[c] = scale[c];
+        coef[cin + c] = training ? dbeta[c] * inv_n : 0.f;
+        coef[2 * cin + c] = training ? mean_rstd[cin + c] * dgamma[c] * inv_n : 0.f;
+        coef[3 * cin + c] = mean_rstd[c];
+    }
+}
+}  // namespace
+
+extern "C" int mivp_uphead_dx_prep(const float* conv_w, const float* scale, const float* mean_rstd, const float* dgamma,
+                                   const float* dbeta, double n_hr, int32_t training, int32_t Cout, int32_t Cin, void* wc,
+                                   float* coef, mivp_stream_t stream) {
+    MIVP_REQUIRE(conv_w && scale && mean_rstd && wc && coef && Cout >= 1 && Cin >= 1 && 27 * Cout <= 64 && n_hr > 0);
+    MIVP_REQUIRE(!training || (dgamma && dbeta));
+    const int cp = (Cin + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_uphead_dx_prep, dim3(1), dim3(256), 0, (hipStream_t)stream, conv_w, scale, mean_rstd, dgamma, dbeta,
+                       (float)(1.0 / n_hr), (int)training, (int)Cout, (int)Cin, cp, (bf16_t*)wc, coef);
+    return mivp_check_launch("uphead_dx_prep");
+}
+
 extern "C" int mivp_uphead_fold(const float* conv_w, const float* scale, const float* shift, int32_t Cout, int32_t Cin,
                                 void* wf, mivp_stream_t stream) {
     MIVP_REQUIRE(conv_w && scale && shift && wf);

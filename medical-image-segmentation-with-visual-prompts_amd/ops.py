@@ -230,17 +230,13 @@ def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training):
     """Gradient w.r.t. the low-res x through upsample -> BatchNorm -> conv (see k_uphead_dx)."""
     B, h, w, d, Cc = x.shape
     cout = conv_w.shape[0]
-    n_hr = float(8 * B * h * w * d)
-    wc = torch.zeros((round_up(Cc, 16), 64), dtype=torch.float32, device=x.device)
-    wc[:Cc, :27 * cout] = conv_w.detach().float().reshape(cout, Cc, 27).permute(1, 2, 0).reshape(Cc, 27 * cout)
-    coef = torch.zeros((4, Cc), dtype=torch.float32, device=x.device)
-    coef[0] = scale
-    if training:
-        coef[1] = dbeta / n_hr
-        coef[2] = mean_rstd[Cc:] * dgamma / n_hr
-    coef[3] = mean_rstd[:Cc]
+    wc = torch.empty((round_up(Cc, 16), 64), dtype=BF16, device=x.device)
+    coef = torch.empty((4, Cc), dtype=torch.float32, device=x.device)
+    L.call("mivp_uphead_dx_prep", L.ptr(conv_w.detach().float().contiguous()), L.ptr(scale), L.ptr(mean_rstd),
+           L.ptr(dgamma if training else None), L.ptr(dbeta if training else None), C.c_double(8.0 * B * h * w * d),
+           C.c_int32(1 if training else 0), C.c_int32(cout), C.c_int32(Cc), L.ptr(wc), L.ptr(coef), L.stream())
     dx = torch.empty_like(x)
-    L.call("mivp_uphead_dx", L.ptr(D), L.ptr(wc.to(BF16).contiguous()), L.ptr(x), L.ptr(coef), C.c_int32(B), C.c_int32(h),
+    L.call("mivp_uphead_dx", L.ptr(D), L.ptr(wc), L.ptr(x), L.ptr(coef), C.c_int32(B), C.c_int32(h),
            C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(dx), L.stream())
     return dx
 
