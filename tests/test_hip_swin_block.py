@@ -103,3 +103,55 @@ def test_block_forward_real_sizes(window, dims, C, heads, n_prompt, shift):
     err = rel_l2(got, want)
     assert err < 6e-3, err
     assert float((got - want).abs().max()) < 8e-2
+
+
+@pytest.mark.parametrize("gain,shift,n_prompt", [(6.0, (3, 3, 3), 64), (12.0, (0, 0, 0), 0), (12.0, (3, 3, 3), 64)])
+def test_block_sharp_softmax(gain, shift, n_prompt):
+    """Large logits with a wide dynamic range (to_q / to_k scaled by ``gain``: logits x gain^2, |logit| up to several hundred
+    in log2 units): the lazily refreshed reference point of the online softmax has to rescale again and again, nearly
+    one-hot rows and fully suppressed keys appear, and the padding keys (excluded through a -30000 bias instead of a test)
+    must stay at exactly zero weight.  Forward against the oracle, then input / prompt gradients through both backward
+    passes (which restart from the stored log-sum-exp)."""
+    import mivp_amd
+    from mivp_amd import swin_ops
+    from oracle import swin_ref as S
+    from oracle.unetr_ref import _block_state
+    window, dims, C, heads = (7, 7, 7), (14, 14, 14), 48, 4
+    gen = torch.Generator().manual_seed(7)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, max(n_prompt, 1), n_prompt > 0, gen)
+    sd["attn.to_q.weight"] = sd["attn.to_q.weight"] * gain
+    sd["attn.to_k.weight"] = sd["attn.to_k.weight"] * gain
+    sd = _rounded_state(sd)
+    x = _bf16_round(torch.randn(1, C, *dims, generator=gen)).requires_grad_(True)
+    prm = (0.5 * torch.randn(n_prompt, C, generator=gen)).requires_grad_(True) if n_prompt else None
+    want = S.swin_block(x, prm, sd, "", window, shift, heads)
+    dy = _bf16_round(torch.randn(want.shape, generator=gen))
+    want.backward(dy)
+    # conditioning yardstick: how far the fp32 oracle's own outputs move when its input carries bf16-level relative noise
+    xn = (x.detach() * (1 + 2.0 ** -9 * torch.randn(x.shape, generator=gen))).requires_grad_(True)
+    pn = prm.detach().clone().requires_grad_(True) if n_prompt else None
+    wantn = S.swin_block(xn, pn, sd, "", window, shift, heads)
+    wantn.backward(dy)
+    yard_y = rel_l2(wantn.detach(), want.detach())
+    yard_dx = rel_l2(xn.grad, x.grad)
+    yard_dp = rel_l2(pn.grad, prm.grad) if n_prompt else 0.0
+    dev = torch.device("cuda")
+    w = swin_ops.weights_from_state(sd, "", heads, 64, n_prompt, dev, need_bwd=True)
+    xc = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
+    pd = None if prm is None else prm.detach().to(dev)
+    y, saved = swin_ops.swin_block_forward(xc, pd, w, None, window, shift, save=True)
+    dyc = dy.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
+    dx, dp, _ = swin_ops.swin_block_backward(saved, w, pd, dyc, True, n_prompt > 0)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    assert torch.isfinite(got).all()
+    # sharper softmax rows amplify the bf16 rounding of x, q and k (a logit error that grows with the gain decides between
+    # near-ties): the bar is 3x the oracle's own sensitivity to 2^-9 input noise, or the unit-gain bars where that is small
+    e_y = rel_l2(got, want.detach())
+    e_dx = rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), x.grad)
+    assert e_y < max(1.5e-2, 3 * yard_y), (e_y, yard_y)
+    assert e_dx < max(4e-2, 3 * yard_dx), (e_dx, yard_dx)
+    if n_prompt:
+        e_dp = rel_l2(dp.float().cpu(), prm.grad)
+        assert e_dp < max(4e-2, 3 * yard_dp), (e_dp, yard_dp)
