@@ -61,24 +61,54 @@ MIVP_DEV PieceAddr piece_setup(const MivpOperandDesc& o, int c, int C) {
     return p;
 }
 
-MIVP_DEV bf16x4 piece_load(const MivpOperandDesc& o, const PieceAddr& p, const bf16_t* __restrict__ base, long t, long T,
+// Where token t sits in each operand's token space, kept as 32-bit counters that advance with the token index: decoding
+// t with 64-bit divisions for every 8-byte piece (five per conv-tap piece) was ~10x the MFMA time of a chunk.
+struct TokPos {
+    long t;                      // token index
+    int h, w, d;                 // mode 2: voxel coordinates (the batch index is not needed: bounds are per volume)
+    long win; int n;             // mode 1: window-head row block, row inside it
+};
+
+MIVP_DEV void tokpos_init(TokPos& s, long t, const MivpOperandDesc& oa, const MivpOperandDesc& ob) {
+    s.t = t;
+    s.h = s.w = s.d = 0; s.win = 0; s.n = 0;
+    const MivpOperandDesc& o2 = oa.mode == 2 ? oa : ob;
+    if (o2.mode == 2) {
+        long r = t;
+        s.d = (int)(r % o2.dims[2]); r /= o2.dims[2];
+        s.w = (int)(r % o2.dims[1]); r /= o2.dims[1];
+        s.h = (int)(r % o2.dims[0]);
+    }
+    const MivpOperandDesc& o1 = oa.mode == 1 ? oa : ob;
+    if (o1.mode == 1) { s.win = t / o1.rows; s.n = (int)(t - s.win * o1.rows); }
+}
+
+MIVP_DEV void tokpos_advance(TokPos& s, int step, const MivpOperandDesc& oa, const MivpOperandDesc& ob) {
+    s.t += step;
+    const MivpOperandDesc& o2 = oa.mode == 2 ? oa : ob;
+    if (o2.mode == 2) {
+        s.d += step;
+        while (s.d >= o2.dims[2]) { s.d -= o2.dims[2]; if (++s.w >= o2.dims[1]) { s.w = 0; if (++s.h >= o2.dims[0]) s.h = 0; } }
+    }
+    const MivpOperandDesc& o1 = oa.mode == 1 ? oa : ob;
+    if (o1.mode == 1) {
+        s.n += step;
+        while (s.n >= o1.rows) { s.n -= o1.rows; ++s.win; }
+    }
+}
+
+MIVP_DEV bf16x4 piece_load(const MivpOperandDesc& o, const PieceAddr& p, const bf16_t* __restrict__ base, const TokPos& s, long T,
                            int C) {
+    const long t = s.t;
     if (!p.col_ok || t >= T) return zero4();
     if (o.mode == 0) return ld4(base + t * o.ld + p.col_off);
-    if (o.mode == 1) {
-        const long w = t / o.rows;
-        const int n = (int)(t - w * o.rows);
-        return ld4(base + (w * (C / o.hd)) * o.rows * o.hd + (long)n * o.hd + p.col_off);
-    }
+    if (o.mode == 1) return ld4(base + (s.win * (C / o.hd)) * o.rows * o.hd + (long)s.n * o.hd + p.col_off);
     const int D = o.dims[2], W = o.dims[1], H = o.dims[0];
-    long r = t;
-    const int d = (int)(r % D); r /= D;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int hh = h + p.dh, ww = w + p.dw, dd = d + p.dd;
+    const int hh = s.h + p.dh, ww = s.w + p.dw, dd = s.d + p.dd;
     if ((unsigned)hh >= (unsigned)H || (unsigned)ww >= (unsigned)W || (unsigned)dd >= (unsigned)D) return zero4();
     return ld4(base + (t + ((long)p.dh * W + p.dw) * D + p.dd) * o.ld + p.col_off);
 }
+
 
 __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                  float* __restrict__ part, int chunks_per_split) {
@@ -86,13 +116,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
     char* As = smem;
     char* Bs = smem + TN_TOK * TN_BLK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * TN_BLK, n0 = blockIdx.z * TN_BLK;
+    // grid = (N blocks, M blocks, token splits): the blocks that share a token range are neighbours in dispatch order and
+    // stream it in step, so the operands come out of L2 (with the split index fastest every 64-column block of a conv
+    // weight gradient re-read dy and its tap-displaced x from HBM: 4.0 ms for the 144->48 conv at 48^3, 41 TFLOP/s)
+    const int m0 = blockIdx.y * TN_BLK, n0 = blockIdx.x * TN_BLK;
     const int cp = tid & 15, r0 = tid >> 4;                    // column piece (4 channels), first row
     const PieceAddr pa = piece_setup(d.a, m0 + 4 * cp, d.M);
     const PieceAddr pb = piece_setup(d.b, n0 + 4 * cp, d.N);
 
     const long nchunks = (d.T + TN_TOK - 1) / TN_TOK;
-    const long c_lo = (long)blockIdx.x * chunks_per_split;
+    const long c_lo = (long)blockIdx.z * chunks_per_split;
     long c_hi = c_lo + chunks_per_split;
     if (c_hi > nchunks) c_hi = nchunks;
 
@@ -103,12 +136,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
         for (int j = 0; j < 4; ++j) acc[i][j] = fzero4();
 
     bf16x4 ra[8], rb[8];
-    auto fetch = [&](long chunk) {
-        const long t0 = chunk * TN_TOK + r0;
+    TokPos pos;                                               // token c_lo * 128 + r0, then +16 per piece, chunk after chunk
+    tokpos_init(pos, c_lo * TN_TOK + r0, d.a, d.b);
+    auto fetch = [&](long) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            ra[i] = piece_load(d.a, pa, a, t0 + 16 * i, d.T, d.M);
-            rb[i] = piece_load(d.b, pb, b, t0 + 16 * i, d.T, d.N);
+            ra[i] = piece_load(d.a, pa, a, pos, d.T, d.M);
+            rb[i] = piece_load(d.b, pb, b, pos, d.T, d.N);
+            tokpos_advance(pos, 16, d.a, d.b);
         }
     };
     // where this thread's pieces go: token row r0 + 16 i, channels 4cp .. 4cp+3
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
         }
     }
     __syncthreads();
-    float* dst = part + (long)blockIdx.x * d.M * d.N;
+    float* dst = part + (long)blockIdx.z * d.M * d.N;
     for (int e = tid; e < TN_BLK * TN_BLK; e += 256) {
         const int m = m0 + (e >> 6), n = n0 + (e & 63);
         if (m < d.M && n < d.N) dst[(long)m * d.N + n] = red[e];
@@ -236,7 +271,7 @@ extern "C" int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* 
     int cps;
     const int splits = tn_splits(d, &cps);
     MIVP_REQUIRE(ws_bytes >= (size_t)splits * d->M * d->N * sizeof(float));
-    const dim3 grid(splits, (d->M + TN_BLK - 1) / TN_BLK, (d->N + TN_BLK - 1) / TN_BLK);
+    const dim3 grid((d->N + TN_BLK - 1) / TN_BLK, (d->M + TN_BLK - 1) / TN_BLK, splits);
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)a, (const bf16_t*)b,
                        (float*)workspace, cps);
     const long total = (long)d->M * d->N;
