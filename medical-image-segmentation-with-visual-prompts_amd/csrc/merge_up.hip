@@ -19,13 +19,16 @@ MIVP_DEV MergeTok merge_token(const MivpMergeDesc& d, long t) {
     const long ovol = (long)d.odims[0] * d.odims[1] * d.odims[2];
     const long T = (long)d.B * ovol;
     m.live = t < T;
-    const long tt = m.live ? t : 0;
-    m.b = tt / ovol;
-    long rem = tt - m.b * ovol;
-    m.o[0] = (int)(rem / ((long)d.odims[1] * d.odims[2]));
-    rem -= (long)m.o[0] * d.odims[1] * d.odims[2];
-    m.o[1] = (int)(rem / d.odims[2]);
-    m.o[2] = (int)(rem - (long)m.o[1] * d.odims[2]);
+    // token counts fit 32 bits (checked on the host): unsigned 32-bit divisions, a fraction of the cost of 64-bit ones
+    const unsigned tt = m.live ? (unsigned)t : 0u;
+    const unsigned ov = (unsigned)ovol, o12 = (unsigned)(d.odims[1] * d.odims[2]);
+    const unsigned bb = tt / ov;
+    unsigned rem = tt - bb * ov;
+    m.b = bb;
+    m.o[0] = (int)(rem / o12);
+    rem -= (unsigned)m.o[0] * o12;
+    m.o[1] = (int)(rem / (unsigned)d.odims[2]);
+    m.o[2] = (int)(rem - (unsigned)m.o[1] * (unsigned)d.odims[2]);
     return m;
 }
 
@@ -127,6 +130,7 @@ extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const
     const int kC = (d->merge_last ? 8 : 4) * d->C;
     const int KS = (kC + 31) / 32;
     const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
+    MIVP_REQUIRE(T < (1L << 31));                               // merge_token decodes in 32 bits
     const unsigned gx = (unsigned)((T + 63) / 64);
     const int n_tiles = (d->Cout + 15) / 16;
     int ny = (int)((1024 + gx - 1) / gx);                    // aim at >= 1024 workgroups
@@ -434,6 +438,7 @@ extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, cons
     MIVP_REQUIRE(d->C % 8 == 0 && d->Cout % 8 == 0);
     const int NS = (d->Cout + 31) / 32;
     const long T = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2];
+    MIVP_REQUIRE(T < (1L << 31));                               // merge_token decodes in 32 bits
     const unsigned gx = (unsigned)((T + 63) / 64);
     const int kC = (d->merge_last ? 8 : 4) * d->C, n_ct = (kC + 15) / 16;
     int ny = (int)((1024 + gx - 1) / gx);

@@ -18,11 +18,13 @@ MIVP_DEV TokInfo token_info(const MivpSwinDesc& d, long t) {
     TokInfo ti;
     const long T = (long)d.B * d.P * d.Nqp;
     ti.live = t < T;
-    ti.tt = ti.live ? t : 0;
-    ti.bp = ti.tt / d.Nqp;
-    ti.slot = (int)(ti.tt - ti.bp * d.Nqp);
-    ti.pw = (int)(ti.bp % d.P);
-    ti.b = ti.bp / d.P;
+    const unsigned tu = ti.live ? (unsigned)t : 0u;          // T fits 32 bits (bwd_checks): 32-bit divisions, not 64-bit ones
+    const unsigned bpu = tu / (unsigned)d.Nqp;
+    ti.tt = tu;
+    ti.bp = bpu;
+    ti.slot = (int)(tu - bpu * (unsigned)d.Nqp);
+    ti.pw = (int)(bpu % (unsigned)d.P);
+    ti.b = bpu / (unsigned)d.P;
     return ti;
 }
 }  // namespace
@@ -959,6 +961,7 @@ static int bwd_checks(const MivpSwinDesc* d) {
     MIVP_REQUIRE(d->B > 0 && d->C > 0 && d->heads > 0 && d->P > 0);
     MIVP_REQUIRE(d->C % 8 == 0 && d->C % d->heads == 0 && (d->C / d->heads) % 4 == 0);
     MIVP_REQUIRE(d->Nqp % 16 == 0 && d->Npp % 16 == 0 && d->Nkp % 32 == 0 && d->augp % 4 == 0);
+    MIVP_REQUIRE((long)d->B * d->P * d->Nqp < (1L << 31));      // kernels decode token indices in 32 bits
     return MIVP_OK;
 }
 

@@ -579,11 +579,12 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     const long T = (long)d.B * d.P * d.Nqp;
     const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
     const bool live = t < T;
-    const long tt = live ? t : 0;
-    const long bp = tt / d.Nqp;
-    const int slot = (int)(tt - bp * d.Nqp);
-    const int pw = (int)(bp % d.P);
-    const long b = bp / d.P;
+    const unsigned tt = live ? (unsigned)t : 0u;             // T = B*P*Nqp fits 32 bits (checked on the host): 32-bit divisions
+    const unsigned bpu = tt / (unsigned)d.Nqp;
+    const long bp = bpu;
+    const int slot = (int)(tt - bpu * (unsigned)d.Nqp);
+    const int pw = (int)(bpu % (unsigned)d.P);
+    const long b = bpu / (unsigned)d.P;
     const int src = live ? tok_src[pw * d.Nqp + slot] : -2;
     const int dst = live ? tok_dst[pw * d.Nqp + slot] : -1;
     bf16x8 wreg[PCS];
