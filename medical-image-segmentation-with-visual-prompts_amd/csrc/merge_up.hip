@@ -245,14 +245,15 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     for (long it = gtid; it < items; it += stride) {
-        const long vox = it / Gx;
-        const int cg = (int)(it - vox * Gx);
-        const long b = vox / ivol;
-        long rem = vox - b * ivol;
-        const int ih = (int)(rem / ((long)d.idims[1] * d.idims[2]));
-        rem -= (long)ih * d.idims[1] * d.idims[2];
-        const int iw = (int)(rem / d.idims[2]);
-        const int id = (int)(rem - (long)iw * d.idims[2]);
+        const unsigned vox = (unsigned)it / (unsigned)Gx;     // host checks items < 2^31: 32-bit decode
+        const int cg = (int)((unsigned)it - vox * (unsigned)Gx);
+        const unsigned b = vox / (unsigned)ivol;
+        unsigned rem = vox - b * (unsigned)ivol;
+        const unsigned i12 = (unsigned)(d.idims[1] * d.idims[2]);
+        const int ih = (int)(rem / i12);
+        rem -= (unsigned)ih * i12;
+        const int iw = (int)(rem / (unsigned)d.idims[2]);
+        const int id = (int)(rem - (unsigned)iw * (unsigned)d.idims[2]);
         const int ic[3] = {ih, iw, id};
         int cand[3][8];
         float cw[3][8];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16
             for (int bb = 0; bb < ncand[1]; ++bb)
                 for (int c = 0; c < ncand[2]; ++c) {
                     const float wgt = cw[0][a] * cw[1][bb] * cw[2][c];
-                    const long ov = ((b * d.odims[0] + cand[0][a]) * (long)d.odims[1] + cand[1][bb]) * d.odims[2] + cand[2][c];
+                    const long ov = (((long)b * d.odims[0] + cand[0][a]) * (long)d.odims[1] + cand[1][bb]) * d.odims[2] + cand[2][c];
                     const bf16x8 v = ld8(dy + ov * Ct + cg * 8);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) acc[i] += wgt * (float)v[i];
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16_t)acc[i];
-        st8(dx + vox * d.Cx + cg * 8, o);
+        st8(dx + (long)vox * d.Cx + cg * 8, o);
     }
 }
 
@@ -299,8 +300,9 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_skip(MivpUpcatDesc d, const b
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     for (long it = gtid; it < items; it += stride) {
-        const long vox = it / Gs;
-        const int cg = (int)(it - vox * Gs);
+        const unsigned vu = (unsigned)it / (unsigned)Gs;       // host checks items < 2^31
+        const int cg = (int)((unsigned)it - vu * (unsigned)Gs);
+        const long vox = vu;
         st8(dskip + vox * d.Cs + cg * 8, ld8(dy + vox * Ct + d.Cx + cg * 8));
     }
 }
@@ -310,6 +312,7 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
     MIVP_REQUIRE(d->Cx % 8 == 0 && d->Cs % 8 == 0);
     if (dx) {
         const long items = (long)d->B * d->idims[0] * d->idims[1] * d->idims[2] * (d->Cx / 8);
+        MIVP_REQUIRE(items < (1L << 31));                        // 32-bit decode in the kernel
         const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
         hipLaunchKernelGGL(k_upcat_bwd_x, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy, (bf16_t*)dx);
         int rc = mivp_check_launch("upcat_bwd_x");
@@ -317,6 +320,7 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
     }
     if (dskip && d->Cs > 0) {
         const long items = (long)d->B * d->odims[0] * d->odims[1] * d->odims[2] * (d->Cs / 8);
+        MIVP_REQUIRE(items < (1L << 31));
         const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
         hipLaunchKernelGGL(k_upcat_bwd_skip, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy,
                            (bf16_t*)dskip);

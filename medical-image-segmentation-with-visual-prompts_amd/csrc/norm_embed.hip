@@ -10,16 +10,24 @@
 //   thread keeps one channel group for its whole grid-stride walk.
 //   mode 0: per-channel sum / sum of squares -> part[block][2C]     mode 1: affine + bf16 store
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, const float* __restrict__ x,
+template <int mode, bool CIN1>
+__global__ __launch_bounds__(256, CIN1 ? 8 : 4) void k_patch_embed(MivpEmbedDesc d, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      float* __restrict__ part, bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = d.C, Cin = d.Cin, G = C / 8;
-    float* wl = reinterpret_cast<float*>(smem);               // [C][Cin*8]
-    float* lsum = wl + C * Cin * 8;                            // [256 * 16] reduction scratch
+    const int C = d.C, Cin = CIN1 ? 1 : d.Cin, G = C / 8;     // CIN1: the CT configurations, offsets fold into immediates
+    // weights in LDS as [channel group][8 channels][Cin*8 taps], group stride padded by 4 floats: the (at most G) distinct
+    // groups of a wave read different banks, all lanes of one group broadcast.  Keeping them out of registers leaves
+    // the kernel at 8 waves/SIMD, which is what hides the latency of the strided x loads.
+    const int gstride = 64 * Cin + 4;
+    float* wl = reinterpret_cast<float*>(smem);               // [G][gstride]
+    float* lsum = wl + G * gstride;                            // [256 * 16] reduction scratch
     const int tid = threadIdx.x;
-    for (int i = tid; i < C * Cin * 8; i += 256) wl[i] = w[i];
+    for (int i = tid; i < C * Cin * 8; i += 256) {
+        const int g = i / (64 * Cin);
+        wl[g * gstride + (i - g * 64 * Cin)] = w[i];
+    }
     __syncthreads();
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2];
     const int oh = H / 2, ow = W / 2, od = D / 2;
@@ -28,53 +36,37 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
     const long gtid = (long)blockIdx.x * 256 + tid;
     const long stride = (long)gridDim.x * 256;
     const int cg = (int)(gtid % G);
+    const float* wg = wl + cg * gstride;
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    // single-channel volumes (the CT configurations): the thread's 8 x 8 weights live in registers for its whole walk
-    float wreg[8][8];
-    if (Cin == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wreg[i][k] = wl[(cg * 8 + i) * 8 + k];
-    }
+    const unsigned uovol = (unsigned)ovol, uwd = (unsigned)(ow * od);      // host checks items < 2^31: 32-bit decode
     for (long it = gtid; it < items; it += stride) {
-        const long vox = it / G;
-        const long b = vox / ovol;
-        long rem = vox - b * ovol;
-        const int h = (int)(rem / ((long)ow * od));
-        rem -= (long)h * ow * od;
-        const int ww = (int)(rem / od);
-        const int z = (int)(rem - (long)ww * od);
+        const unsigned vox = (unsigned)it / (unsigned)G;
+        const unsigned b = vox / uovol;
+        unsigned rem = vox - b * uovol;
+        const int h = (int)(rem / uwd);
+        rem -= (unsigned)h * uwd;
+        const int ww = (int)(rem / (unsigned)od);
+        const int z = (int)(rem - (unsigned)ww * (unsigned)od);
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
-        if (Cin == 1) {
-            const float* xb = x + b * ivol;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const float2 xv = *reinterpret_cast<const float2*>(xb + ((long)(2 * h + a) * W + (2 * ww + bb)) * D + 2 * z);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] += xv.x * wreg[i][a * 4 + bb * 2] + xv.y * wreg[i][a * 4 + bb * 2 + 1];
-                }
-        } else
+        asm volatile("" ::: "memory");                            // keep the weight reads in the loop (LICM would pin 64 VGPRs)
         for (int ci = 0; ci < Cin; ++ci) {
-            const float* xb = x + (b * Cin + ci) * ivol;
+            const float* xb = x + ((long)b * Cin + ci) * ivol + ((long)(2 * h) * W + 2 * ww) * D + 2 * z;
+            const float2 x00 = *reinterpret_cast<const float2*>(xb);
+            const float2 x01 = *reinterpret_cast<const float2*>(xb + D);
+            const float2 x10 = *reinterpret_cast<const float2*>(xb + (long)W * D);
+            const float2 x11 = *reinterpret_cast<const float2*>(xb + (long)W * D + D);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const float2 xv = *reinterpret_cast<const float2*>(xb + ((long)(2 * h + a) * W + (2 * ww + bb)) * D + 2 * z);
-                    const int wo = ci * 8 + a * 4 + bb * 2;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float* wr = wl + (cg * 8 + i) * Cin * 8 + wo;
-                        acc[i] += xv.x * wr[0] + xv.y * wr[1];
-                    }
-                }
+            for (int i = 0; i < 8; ++i) {
+                const float4 wa = *reinterpret_cast<const float4*>(wg + (i * Cin + ci) * 8);
+                const float4 wb = *reinterpret_cast<const float4*>(wg + (i * Cin + ci) * 8 + 4);
+                acc[i] += x00.x * wa.x + x00.y * wa.y + x01.x * wa.z + x01.y * wa.w +
+                          x10.x * wb.x + x10.y * wb.y + x11.x * wb.z + x11.y * wb.w;
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);    // at most two channels' weights in flight
+            }
         }
         if (mode == 0) {
 #pragma unroll
@@ -83,7 +75,7 @@ __global__ __launch_bounds__(256) void k_patch_embed(MivpEmbedDesc d, int mode, 
             bf16x8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (bf16_t)(acc[i] * scale[cg * 8 + i] + shift[cg * 8 + i]);
-            st8(y + vox * C + cg * 8, o);
+            st8(y + (long)vox * C + cg * 8, o);
         }
     }
     if (mode == 0) block_reduce_groups(lsum, s1, s2, G, C, (long)blockIdx.x * 256, part + (long)blockIdx.x * 2 * C);
@@ -96,9 +88,13 @@ extern "C" int mivp_patch_embed(const MivpEmbedDesc* d, int mode, const float* x
     MIVP_REQUIRE(d->dims[0] % 2 == 0 && d->dims[1] % 2 == 0 && d->dims[2] % 2 == 0);
     MIVP_REQUIRE((d->nblk * 256) % (d->C / 8) == 0);
     MIVP_REQUIRE(mode == 0 ? part != nullptr : (y && scale && shift));
-    const size_t lds = ((size_t)d->C * d->Cin * 8 + 256 * 16) * sizeof(float);
-    hipLaunchKernelGGL(k_patch_embed, dim3(d->nblk), dim3(256), lds, (hipStream_t)stream, *d, mode, x, w, bias, scale,
-                       shift, part, (bf16_t*)y);
+    MIVP_REQUIRE((long)d->B * (d->dims[0] / 2) * (d->dims[1] / 2) * (d->dims[2] / 2) * (d->C / 8) < (1L << 31));   // 32-bit decode
+    const size_t lds = ((size_t)(d->C / 8) * (64 * d->Cin + 4) + 256 * 16) * sizeof(float);
+#define PE_LAUNCH(M, S) hipLaunchKernelGGL((k_patch_embed<M, S>), dim3(d->nblk), dim3(256), lds, (hipStream_t)stream, *d, x, w, \
+                                           bias, scale, shift, part, (bf16_t*)y)
+    if (mode == 0) { if (d->Cin == 1) PE_LAUNCH(0, true); else PE_LAUNCH(0, false); }
+    else           { if (d->Cin == 1) PE_LAUNCH(1, true); else PE_LAUNCH(1, false); }
+#undef PE_LAUNCH
     return mivp_check_launch("patch_embed");
 }
 
@@ -111,17 +107,17 @@ __global__ __launch_bounds__(256) void k_patch_im2col(MivpEmbedDesc d, const flo
     const long items = (long)d.B * ovol * Cin * 4;
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
         const int ab = (int)(it & 3);
-        long r = it >> 2;
-        const int ci = (int)(r % Cin);
-        const long vox = r / Cin;
-        const long b = vox / ovol;
-        long rem = vox - b * ovol;
-        const int h = (int)(rem / ((long)ow * od));
-        rem -= (long)h * ow * od;
-        const int ww = (int)(rem / od);
-        const int z = (int)(rem - (long)ww * od);
-        const float2 xv = *reinterpret_cast<const float2*>(x + (b * Cin + ci) * ivol + ((long)(2 * h + (ab >> 1)) * W + (2 * ww + (ab & 1))) * D + 2 * z);
-        bf16_t* o = p + vox * (Cin * 8) + ci * 8 + ab * 2;
+        const unsigned r = (unsigned)(it >> 2);                    // host checks items < 2^31
+        const unsigned vox = r / (unsigned)Cin;
+        const int ci = (int)(r - vox * (unsigned)Cin);
+        const unsigned b = vox / (unsigned)ovol;
+        unsigned rem = vox - b * (unsigned)ovol;
+        const int h = (int)(rem / (unsigned)(ow * od));
+        rem -= (unsigned)h * (unsigned)(ow * od);
+        const int ww = (int)(rem / (unsigned)od);
+        const int z = (int)(rem - (unsigned)ww * (unsigned)od);
+        const float2 xv = *reinterpret_cast<const float2*>(x + ((long)b * Cin + ci) * ivol + ((long)(2 * h + (ab >> 1)) * W + (2 * ww + (ab & 1))) * D + 2 * z);
+        bf16_t* o = p + (long)vox * (Cin * 8) + ci * 8 + ab * 2;
         o[0] = (bf16_t)xv.x;
         o[1] = (bf16_t)xv.y;
     }
@@ -131,6 +127,7 @@ extern "C" int mivp_patch_im2col(const MivpEmbedDesc* d, const float* x, void* p
     MIVP_REQUIRE(d && x && p && d->Cin > 0);
     MIVP_REQUIRE(d->dims[0] % 2 == 0 && d->dims[1] % 2 == 0 && d->dims[2] % 2 == 0);
     const long items = (long)d->B * (d->dims[0] / 2) * (d->dims[1] / 2) * (d->dims[2] / 2) * d->Cin * 4;
+    MIVP_REQUIRE(items < (1L << 31));                            // 32-bit decode
     const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
     hipLaunchKernelGGL(k_patch_im2col, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, x, (bf16_t*)p);
     return mivp_check_launch("patch_im2col");

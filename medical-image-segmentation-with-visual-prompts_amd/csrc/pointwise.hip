@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd(const float* __restrict__
     const int G = C / 8;
     const long items = n_vox * G;
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const long v = it / G;
+        const long v = (unsigned)it / (unsigned)G;                 // host checks items < 2^31
         const int cg = (int)(it - v * G);
         float g[COUT];
 #pragma unroll
@@ -81,6 +81,7 @@ extern "C" int mivp_pointwise_bwd(const float* dy, const float* w, int64_t n_vox
                                   mivp_stream_t stream) {
     MIVP_REQUIRE(dy && w && dx && n_vox > 0 && C > 0 && C % 8 == 0 && Cout >= 1 && Cout <= PW_MAXCO);
     const long items = n_vox * (C / 8);
+    MIVP_REQUIRE(items < (1L << 31));                            // 32-bit decode in the kernel
     const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     const size_t lds = (size_t)Cout * C * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

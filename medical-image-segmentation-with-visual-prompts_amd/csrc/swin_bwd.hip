@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256) void k_win_attn_delta(MivpSwinDesc d, const bf
     const int hd = d.C / d.heads;
     const long tokens = (long)d.B * d.P * d.Nqp, total = tokens * d.heads;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int head = (int)(i % d.heads);
-        const long tok = i / d.heads;
-        const long bp = tok / d.Nqp;
-        const int qrow = (int)(tok - bp * d.Nqp);
+        const unsigned tok = (unsigned)i / (unsigned)d.heads;        // host checks total < 2^31: 32-bit decode
+        const int head = (int)((unsigned)i - tok * (unsigned)d.heads);
+        const long bp = tok / (unsigned)d.Nqp;
+        const int qrow = (int)(tok - (unsigned)bp * (unsigned)d.Nqp);
         const long off = tok * (long)d.C + head * hd;
         float acc = 0.f;
         for (int j = 0; j < hd; j += 4) {
@@ -1002,6 +1002,7 @@ extern "C" int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const v
     if (rc) return rc;
     MIVP_REQUIRE(o && d_o && delta);
     const long total = (long)d->B * d->P * d->heads * d->Nqp;
+    MIVP_REQUIRE(total < (1L << 31));                            // 32-bit decode in the kernel
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(k_win_attn_delta, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)o,
                        (const bf16_t*)d_o, delta);

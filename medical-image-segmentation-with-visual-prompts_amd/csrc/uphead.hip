@@ -66,13 +66,14 @@ __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
     for (long it = gtid; it < items; it += stride) {
-        long rest = it / G;
-        const int seg = (int)(rest % nseg);
-        rest /= nseg;
-        const int p1 = (int)(rest % w);
-        rest /= w;
-        const int p0 = (int)(rest % h);
-        const long b = rest / h;
+        unsigned rest = (unsigned)it / (unsigned)G;               // host checks items < 2^31: 32-bit decode
+        unsigned nx = rest / (unsigned)nseg;
+        const int seg = (int)(rest - nx * (unsigned)nseg);
+        rest = nx; nx = rest / (unsigned)w;
+        const int p1 = (int)(rest - nx * (unsigned)w);
+        rest = nx; nx = rest / (unsigned)h;
+        const int p0 = (int)(rest - nx * (unsigned)h);
+        const long b = nx;
         const int lo = seg * ST_SEG, hi = (lo + ST_SEG) < d ? (lo + ST_SEG) : d;
         float g01[3][3];
         long roff[3][3];
@@ -719,6 +720,7 @@ extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w,
     int rc = uphead_checks(B, h, w, d, C, 1);
     if (rc) return rc;
     MIVP_REQUIRE(x && part);
+    MIVP_REQUIRE((long)B * h * w * ((d + ST_SEG - 1) / ST_SEG) * (C / 8) < (1L << 31));     // 32-bit decode in the kernel
     hipLaunchKernelGGL(k_uphead_stats, dim3(mivp_uphead_nblk(B, h, w, d, C)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (int)B, (int)h, (int)w, (int)d, (int)C, part);
     return mivp_check_launch("uphead_stats");

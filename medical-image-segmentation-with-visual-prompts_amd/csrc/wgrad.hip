@@ -301,10 +301,10 @@ MIVP_DEV LnRow ln_row(const bf16_t* __restrict__ x, const int* __restrict__ tok_
     r.cls = 0;
     r.p = x + t * C;
     if (tok_src) {
-        const long bp = t / Nqp;
-        const int slot = (int)(t - bp * Nqp);
-        const int pw = (int)(bp % P);
-        const long b = bp / P;
+        const unsigned bp = (unsigned)t / (unsigned)Nqp;          // callers check T < 2^31
+        const int slot = (int)((unsigned)t - bp * (unsigned)Nqp);
+        const long b = bp / (unsigned)P;
+        const int pw = (int)(bp - (unsigned)b * (unsigned)P);
         const int src = tok_src[pw * Nqp + slot];
         r.cls = src >= 0 ? 0 : (src == -1 ? 1 : 2);
         r.p = x + (b * vol + (src >= 0 ? src : 0)) * C;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_ln_wgrad(const bf16_t* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gm[i] = gamma[cg * 8 + i]; bt[i] = beta[cg * 8 + i]; s1[i] = 0.f; s2[i] = 0.f; }
     for (long it = gtid; it < items; it += stride) {
-        const long t = it / G;
+        const long t = (unsigned)it / (unsigned)G;                 // host checks items < 2^31
         const float mean = stats[2 * t], rstd = stats[2 * t + 1];
         bf16x8 nv = zero8();
         if (rstd >= 0.f) {
@@ -418,6 +418,7 @@ extern "C" int mivp_ln_wgrad(const void* x, const int32_t* tok_src, const void* 
     MIVP_REQUIRE(x && dn && gamma && beta && stats && n_out && part && T > 0 && C > 0 && C % 8 == 0);
     MIVP_REQUIRE(tok_src == nullptr || (Nqp > 0 && P > 0 && vol > 0 && T % Nqp == 0));
     MIVP_REQUIRE(nblk > 0 && ((long)nblk * 256) % (C / 8) == 0);
+    MIVP_REQUIRE(T * (C / 8) < (1L << 31));                       // 32-bit decode in the kernels
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_ln_rowstats, dim3((unsigned)((T + 15) / 16)), dim3(256), 0, st, (const bf16_t*)x, tok_src, (long)T,
                        (int)C, (int)Nqp, (int)P, (long)vol, eps, stats);
