@@ -10,13 +10,92 @@
 namespace {
 constexpr int LOSS_MAXC = 8;
 // log(1 + e) with e in (0, 1]: the hardware log is accurate to ~1 ulp of the RESULT's magnitude near 1, i.e. an absolute
-// error <= 6e-8 -- far below the 1e-4 gradient tolerance -- and ~20x cheaper than log1pf
-MIVP_DEV float log_sigmoid(float u) { return fminf(u, 0.f) - __logf(1.f + __expf(-fabsf(u))); }
-MIVP_DEV float sigmoid(float u) { return 1.f / (1.f + __expf(-u)); }
+// error <= 6e-8 -- far below the 1e-4 gradient tolerance -- and ~20x cheaper than log1pf.
+// log_sigmoid(+-z) and sigmoid(+-z) share e = exp(-|z|), log(1 + e) and 1 / (1 + e): one exp, one log, one rcp per logit.
+struct Sig { float ls_pos, ls_neg, sg_pos, sg_neg; };          // log_sigmoid(z), log_sigmoid(-z), sigmoid(z), sigmoid(-z)
+MIVP_DEV Sig sig_all(float z) {
+    const float e = __expf(-fabsf(z)), l = __logf(1.f + e), r = __builtin_amdgcn_rcpf(1.f + e);   // v_rcp_f32: 1 ulp
+    Sig g;
+    g.ls_pos = fminf(z, 0.f) - l;
+    g.ls_neg = fminf(-z, 0.f) - l;
+    g.sg_pos = z >= 0.f ? r : e * r;
+    g.sg_neg = z >= 0.f ? e * r : r;
+    return g;
+}
+
+template <int C>
+MIVP_DEV void voxel_stats(const float* zz, int cls, int c0, float gamma, float* acc) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, zz[c]);
+    float den = 0.f, e[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { e[c] = __expf(zz[c] - mx); den += e[c]; }
+    const float inv_den = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (c >= c0) {
+            const float p = e[c] * inv_den, t = (c == cls) ? 1.f : 0.f;
+            acc[3 * c] += p * t;
+            acc[3 * c + 1] += p;
+            acc[3 * c + 2] += t;
+            const Sig g = sig_all(zz[c]);
+            const float bce = zz[c] - zz[c] * t - g.ls_pos;
+            acc[3 * LOSS_MAXC] += __expf(gamma * (c == cls ? g.ls_neg : g.ls_pos)) * bce;     // log_sigmoid(-z (2t - 1))
+        }
+    }
+}
+
+// per-(sample, class) constants of the dice gradient: d(dice mean)/dp_c = qa[c] - (c == cls) * qb[c]
+template <int C>
+MIVP_DEV void dice_consts(const float* __restrict__ st, int c0, float wd, float* qa, float* qb) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        qa[c] = 0.f; qb[c] = 0.f;
+        if (c >= c0) {
+            const float I = st[3 * c], P = st[3 * c + 1], T = st[3 * c + 2];
+            const float Dn = P + T + 1e-5f, Nn = 2.f * I + 1e-5f;
+            qa[c] = wd * (Nn / (Dn * Dn));
+            qb[c] = wd * (2.f / Dn);
+        }
+    }
+}
+
+template <int C>
+MIVP_DEV void voxel_grad(const float* zz, int cls, int c0, float gamma, float wf, const float* qa, const float* qb, float* gz) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, zz[c]);
+    float den = 0.f, p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = __expf(zz[c] - mx); den += p[c]; }
+    const float inv_den = __builtin_amdgcn_rcpf(den);
+    float q[C], pq = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        p[c] *= inv_den;
+        q[c] = qa[c] - ((c == cls) ? qb[c] : 0.f);
+        pq += p[c] * q[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float g = p[c] * (q[c] - pq);                                        // through the softmax
+        if (c >= c0) {
+            const float t = (c == cls) ? 1.f : 0.f, sg = 2.f * t - 1.f;
+            const Sig sv = sig_all(zz[c]);
+            const float w = __expf(gamma * (c == cls ? sv.ls_neg : sv.ls_pos));               // log_sigmoid(-z sg)
+            const float bce = zz[c] - zz[c] * t - sv.ls_pos;
+            g += wf * (w * (sv.sg_pos - t) - bce * gamma * w * sg * (c == cls ? sv.sg_pos : sv.sg_neg));
+        }
+        gz[c] = g;
+    }
+}
 }
 
 // pass 1: per-block partial sums  [3*C (I, P, T per class) + 1 (focal sum)]  for ONE batch element per block row
-template <int C>
+// VEC: four consecutive voxels per thread and iteration through 16-byte loads (vol % 4 == 0): the loads of one iteration
+// are independent, which is what hides the HBM latency of this short grid-stride walk
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restrict__ z, const float* __restrict__ y, long vol,
                                                           int c0, float gamma, int blocks_per_b,
                                                           float* __restrict__ part) {
@@ -25,33 +104,39 @@ __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restric
     float acc[3 * LOSS_MAXC + 1];
 #pragma unroll
     for (int i = 0; i < 3 * LOSS_MAXC + 1; ++i) acc[i] = 0.f;
-    for (long v = (long)blk * 256 + threadIdx.x; v < vol; v += (long)blocks_per_b * 256) {
-        const float* zv = z + ((long)b * vol + v) * C;
-        const int cls = (int)y[(long)b * vol + v];
-        float zz[LOSS_MAXC], mx = -INFINITY;
+    if (VEC) {
+        const long nq = vol >> 2;
+        for (long q = (long)blk * 256 + threadIdx.x; q < nq; q += (long)blocks_per_b * 256) {
+            const long v = (long)b * vol + 4 * q;
+            float zb[4 * C];
 #pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { zz[c] = zv[c]; mx = fmaxf(mx, zz[c]); }
-        float den = 0.f, e[LOSS_MAXC];
-#pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { e[c] = __expf(zz[c] - mx); den += e[c]; }
-        const float inv_den = 1.f / den;
-#pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) {
-            if (c < C && c >= c0) {
-                const float p = e[c] * inv_den, t = (c == cls) ? 1.f : 0.f;
-                acc[3 * c] += p * t;
-                acc[3 * c + 1] += p;
-                acc[3 * c + 2] += t;
-                const float bce = zz[c] - zz[c] * t - log_sigmoid(zz[c]);
-                acc[3 * LOSS_MAXC] += __expf(gamma * log_sigmoid(-zz[c] * (2.f * t - 1.f))) * bce;
+            for (int j = 0; j < C; ++j) {
+                const float4 t4 = *reinterpret_cast<const float4*>(z + v * C + 4 * j);
+                zb[4 * j] = t4.x; zb[4 * j + 1] = t4.y; zb[4 * j + 2] = t4.z; zb[4 * j + 3] = t4.w;
             }
+            const float4 y4 = *reinterpret_cast<const float4*>(y + v);
+            voxel_stats<C>(zb, (int)y4.x, c0, gamma, acc);
+            voxel_stats<C>(zb + C, (int)y4.y, c0, gamma, acc);
+            voxel_stats<C>(zb + 2 * C, (int)y4.z, c0, gamma, acc);
+            voxel_stats<C>(zb + 3 * C, (int)y4.w, c0, gamma, acc);
+        }
+    } else {
+        for (long v = (long)blk * 256 + threadIdx.x; v < vol; v += (long)blocks_per_b * 256) {
+            const float* zv = z + ((long)b * vol + v) * C;
+            float zz[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) zz[c] = zv[c];
+            voxel_stats<C>(zz, (int)y[(long)b * vol + v], c0, gamma, acc);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 3 * LOSS_MAXC + 1; ++i) {
-        float vsum = acc[i];
-        for (int o = 32; o > 0; o >>= 1) vsum += __shfl_xor(vsum, o);
+        float vsum = 0.f;
+        if (i < 3 * C || i == 3 * LOSS_MAXC) {                    // the other columns are never touched: they stay zero
+            vsum = acc[i];
+            for (int o = 32; o > 0; o >>= 1) vsum += __shfl_xor(vsum, o);
+        }
         if (lane == 0) red[wave][i] = vsum;
     }
     __syncthreads();
@@ -94,8 +179,8 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
     }
 }
 
-// pass 2: dz = dL/dz  (f32, same layout as z)
-template <int C>
+// pass 2: dz = dL/dz  (f32, same layout as z); VEC as in pass 1 (a group of four voxels never straddles two samples)
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict__ z, const float* __restrict__ y, long vol,
                                                          int B, int c0, float gamma, const float* __restrict__ stats,
                                                          float* __restrict__ dz) {
@@ -103,44 +188,38 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
     const long total = (long)B * vol;
     const float ncls = (float)(C - c0);
     const float wd = 1.f / ((float)B * ncls), wf = 1.f / ((float)B * ncls * (float)vol);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int b = (int)(i / vol);
-        const float* zv = z + i * C;
-        const int cls = (int)y[i];
-        float zz[LOSS_MAXC], mx = -INFINITY;
+    if (VEC) {
+        const long nq = total >> 2;
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+            const long i = 4 * q;
+            const int b = (int)(i / vol);
+            float zb[4 * C], gb[4 * C];
 #pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { zz[c] = zv[c]; mx = fmaxf(mx, zz[c]); }
-        float den = 0.f, p[LOSS_MAXC];
-#pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) if (c < C) { p[c] = __expf(zz[c] - mx); den += p[c]; }
-        const float inv_den = 1.f / den;
-        float q[LOSS_MAXC], pq = 0.f;
-#pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) {
-            if (c < C) {
-                p[c] *= inv_den;
-                float qc = 0.f;
-                if (c >= c0) {
-                    const float I = stats[b * K + 3 * c], P = stats[b * K + 3 * c + 1], T = stats[b * K + 3 * c + 2];
-                    const float Dn = P + T + 1e-5f, Nn = 2.f * I + 1e-5f;
-                    qc = wd * (Nn / (Dn * Dn) - ((c == cls) ? 2.f / Dn : 0.f));     // d(dice mean)/dp_c
-                }
-                q[c] = qc;
-                pq += p[c] * qc;
+            for (int j = 0; j < C; ++j) {
+                const float4 t4 = *reinterpret_cast<const float4*>(z + i * C + 4 * j);
+                zb[4 * j] = t4.x; zb[4 * j + 1] = t4.y; zb[4 * j + 2] = t4.z; zb[4 * j + 3] = t4.w;
             }
+            const float4 y4 = *reinterpret_cast<const float4*>(y + i);
+            float qa[C], qb[C];
+            dice_consts<C>(stats + b * K, c0, wd, qa, qb);
+            voxel_grad<C>(zb, (int)y4.x, c0, gamma, wf, qa, qb, gb);
+            voxel_grad<C>(zb + C, (int)y4.y, c0, gamma, wf, qa, qb, gb + C);
+            voxel_grad<C>(zb + 2 * C, (int)y4.z, c0, gamma, wf, qa, qb, gb + 2 * C);
+            voxel_grad<C>(zb + 3 * C, (int)y4.w, c0, gamma, wf, qa, qb, gb + 3 * C);
+#pragma unroll
+            for (int j = 0; j < C; ++j)
+                *reinterpret_cast<float4*>(dz + i * C + 4 * j) = make_float4(gb[4 * j], gb[4 * j + 1], gb[4 * j + 2], gb[4 * j + 3]);
         }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int b = (int)(i / vol);
+            float zz[C], gz[C], qa[C], qb[C];
 #pragma unroll
-        for (int c = 0; c < LOSS_MAXC; ++c) {
-            if (c < C) {
-                float gz = p[c] * (q[c] - pq);                                        // through the softmax
-                if (c >= c0) {
-                    const float t = (c == cls) ? 1.f : 0.f, s = 2.f * t - 1.f;
-                    const float w = __expf(gamma * log_sigmoid(-zz[c] * s));
-                    const float bce = zz[c] - zz[c] * t - log_sigmoid(zz[c]);
-                    gz += wf * (w * (sigmoid(zz[c]) - t) - bce * gamma * w * s * sigmoid(zz[c] * s));
-                }
-                dz[i * C + c] = gz;
-            }
+            for (int c = 0; c < C; ++c) zz[c] = z[i * C + c];
+            dice_consts<C>(stats + b * K, c0, wd, qa, qb);
+            voxel_grad<C>(zz, (int)y[i], c0, gamma, wf, qa, qb, gz);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dz[i * C + c] = gz[c];
         }
     }
 }
@@ -170,8 +249,11 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break; \
         case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;              \
     }
-#define L_STATS(CC) hipLaunchKernelGGL((k_dice_focal_stats<CC>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, logits, target, \
-                                       (long)vol, c0, gamma, (int)bpb, part)
+    const bool vec = vol % 4 == 0;                             // 16-byte loads of four voxels
+#define L_STATS(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_stats<CC, true>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, \
+                                                     logits, target, (long)vol, c0, gamma, (int)bpb, part);                    \
+                         else hipLaunchKernelGGL((k_dice_focal_stats<CC, false>), dim3((unsigned)(B * bpb)), dim3(256), 0, st,    \
+                                                 logits, target, (long)vol, c0, gamma, (int)bpb, part); } while (0)
     LOSS_C_SWITCH(L_STATS)
 #undef L_STATS
     int rc = mivp_check_launch("dice_focal_stats");
@@ -179,10 +261,12 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
     hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(1024), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
     rc = mivp_check_launch("dice_focal_finalize");
     if (rc) return rc;
-    const long total = (long)B * vol;
+    const long total = vec ? (long)B * vol / 4 : (long)B * vol;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define L_GRAD(CC) hipLaunchKernelGGL((k_dice_focal_grad<CC>), dim3(grid), dim3(256), 0, st, logits, target, (long)vol, (int)B, \
-                                      c0, gamma, stats, dlogits)
+#define L_GRAD(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_grad<CC, true>), dim3(grid), dim3(256), 0, st, logits, target, \
+                                                    (long)vol, (int)B, c0, gamma, stats, dlogits);                            \
+                        else hipLaunchKernelGGL((k_dice_focal_grad<CC, false>), dim3(grid), dim3(256), 0, st, logits, target,   \
+                                                (long)vol, (int)B, c0, gamma, stats, dlogits); } while (0)
     LOSS_C_SWITCH(L_GRAD)
 #undef L_GRAD
 #undef LOSS_C_SWITCH
