@@ -1,0 +1,103 @@
+"""GPU, world_size 2: the HIP model under DistributedDataParallel, two ranks sharing cuda:0 over gloo.
+
+RCCL refuses two ranks on one device, so on the one-GPU box the collective runs through gloo (host staging);
+everything else is the bench's N>1 path: mivp_amd.train.init_distributed / wrap_ddp / build_optimizer / train_step
+around the product module with its custom autograd functions, frozen parameters and bucket-view gradients.
+Checked per workload: the reduced gradient is the mean of the two ranks' local gradients, replicas stay identical
+after three optimizer steps (DDP's unused-parameter check would raise on the second one), the loss stays finite.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+WORKLOADS = {
+    # name -> (training_mode, encoder prompts, decoder prompts)
+    "downstream_frozen": ("downstream", False, False),
+    "downstream_prompts": ("downstream", True, True),
+    "supervised_all": ("supervised_learning_all", False, False),
+}
+
+
+def _worker(rank, world, port, q, case):
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        import mivp_amd  # noqa: F401
+        from mivp_amd import train
+        from mivp_amd.swin_unetr import SwinUnetR
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        r, _, w = train.init_distributed(dev, "gloo")
+        assert (r, w) == (rank, world)
+        conf, size, batch = train.make_conf("tiny", (7, 7, 7), 0.0)
+        conf.training_mode, conf.use_encoder_prompting, conf.use_decoder_prompting = WORKLOADS[case]
+        torch.manual_seed(0)
+        model = SwinUnetR(conf).to(dev).train()
+        x, y = train.synthetic_batch(conf, batch, size, dev, rank)
+
+        def grads():
+            return {n: p.grad.detach().float().cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+
+        loss = train.step_loss(model(x), conf, y)                 # this replica alone, this rank's shard
+        loss.backward()
+        local = grads()
+        model.zero_grad(set_to_none=True)
+        net = train.wrap_ddp(model, 0)
+        opt = train.build_optimizer(net, conf)
+        train.barrier_sync(dev)
+        loss = train.step_loss(net(x), conf, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        synced = grads()
+        opt.step()
+        last = None
+        for _ in range(2):
+            last = train.train_step(net, opt, conf, x, y)
+        t = train.max_over_ranks(1.0 + rank, dev)
+        params = {n: p.detach().float().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}
+        q.put((rank, None, float(x.sum()), local, synced, params, t, float(last)))
+        train.barrier_sync(dev)
+        torch.distributed.destroy_process_group()
+    except Exception as e:                                         # surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e), 0.0, {}, {}, {}, 0.0, 0.0))
+
+
+@pytest.mark.parametrize("case", list(WORKLOADS))
+def test_two_ranks_one_gpu(case):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] is None, r[1]
+    for p in procs:
+        assert p.exitcode == 0
+    (_, _, sum0, loc0, syn0, par0, t0, l0), (_, _, sum1, loc1, syn1, par1, t1, l1) = res
+    assert sum0 != sum1                                            # shards differ per rank
+    assert t0 == t1 == 2.0                                         # max over ranks of (1.0, 2.0)
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert syn0.keys() == syn1.keys() == loc0.keys() == loc1.keys() and len(syn0) > 0
+    for k in syn0:
+        mean = 0.5 * (loc0[k] + loc1[k])
+        scale = max(float(np.abs(mean).max()), 1e-12)
+        # the HIP backward is deterministic: the second (DDP) backward repeats the local one, the mean is exact up to fp32 rounding
+        assert np.abs(syn0[k] - mean).max() <= 1e-5 * scale + 1e-12, k
+        assert np.array_equal(syn0[k], syn1[k]), k                 # every rank holds the same reduced gradient
+    assert par0.keys() == par1.keys() and len(par0) > 0
+    for k in par0:
+        assert np.array_equal(par0[k], par1[k]), k                 # replicas identical after three steps
