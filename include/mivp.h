@@ -357,7 +357,9 @@ int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t
 /* BatchNorm statistics of upsample(x): part [mivp_uphead_nblk(...)][2C] f32 partial (sum | sum of squares),   */
 /* reduce with mivp_bn_finalize exactly like mivp_bn_stats' output (count = 8*B*h*w*d)                         */
 int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w, int32_t d, int32_t C);
-int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
+/* gx (may be NULL): f32 [B*h*w*d][C] = U^T U x, the 27-point Gram stencil of the upsample applied to x -- the   */
+/* per-cell term mivp_uphead_dx needs for the BatchNorm backward; keeping it saves that kernel a 27-point gather  */
+int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part, float* gx,
                       mivp_stream_t stream);
 /* y [B,2h,2w,2d,Cout] f32 = bias + conv3x3x3(affine(upsample(x))).  wf: bf16 [16*ceil(27*Cout/16)][64], row
  * tap*Cout + co = (weight[co][:, tap] * scale | sum_c weight[co][c, tap] * shift[c] | 0...): the BatchNorm affine
@@ -390,9 +392,10 @@ int mivp_uphead_dx_prep(const float* conv_w, const float* scale, const float* me
 
 /* gradient w.r.t. x [B,h,w,d,C] (bf16) through upsample -> BatchNorm -> conv, all at low resolution:
  *   D with ldD == 64; wc bf16 [16*ceil(C/16)][64] = conv weight as [c][tap*Cout + co] (zero padded);
- *   coef f32 [4][C] = (BN scale | sum(dz)/N | rstd*sum(dz*xhat)/N | batch mean), rows 1-2 zero for eval-mode BN */
-int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, int32_t B, int32_t h, int32_t w,
-                   int32_t d, int32_t C, void* dx, mivp_stream_t stream);
+ *   coef f32 [4][C] = (BN scale | sum(dz)/N | rstd*sum(dz*xhat)/N | batch mean), rows 1-2 zero for eval-mode BN;
+ *   gx: mivp_uphead_stats' optional output for the same x, or NULL (the kernel then gathers the stencil itself) */
+int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, const float* gx, int32_t B, int32_t h,
+                   int32_t w, int32_t d, int32_t C, void* dx, mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* weight gradients: out[M][N] (+)= alpha * sum_t A[t][m] * B[t][n]          */

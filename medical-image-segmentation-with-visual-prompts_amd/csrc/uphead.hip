@@ -54,7 +54,7 @@ MIVP_DEV float gram_w(int p, int m, int n) {                 // (U^T U)[p][p+m] 
 // ST_SEG cells for parallelism (the two A's beyond a segment's ends are recomputed).
 constexpr int ST_SEG = 16;
 __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__ x, int B, int h, int w, int d, int C,
-                                                      float* __restrict__ part) {
+                                                      float* __restrict__ part, float* __restrict__ gx) {
     __shared__ float lds[256 * 16];
     const int G = C / 8;
     const int nseg = (d + ST_SEG - 1) / ST_SEG;
@@ -109,10 +109,17 @@ __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__
             const int cell = dd - 1;               // its three A's are Am (cell-1), Ac (cell), An (cell+1)
             if (cell >= lo && cell < hi) {
                 const float gm = gram_w(cell, -1, d), g0 = gram_w(cell, 0, d), gp = gram_w(cell, 1, d);
+                float q[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    q[i] = gm * Am[i] + g0 * Ac[i] + gp * An[i];     // (U^T U x)[cell]: the Gram stencil applied to x
                     s1[i] += 8.f * xc[i];
-                    s2[i] += xc[i] * (gm * Am[i] + g0 * Ac[i] + gp * An[i]);
+                    s2[i] += xc[i] * q[i];
+                }
+                if (gx) {                                            // kept for k_uphead_dx (BatchNorm backward needs it per cell)
+                    float* o = gx + ((((long)b * h + p0) * w + p1) * d + cell) * C + cg * 8;
+                    *reinterpret_cast<float4*>(o) = make_float4(q[0], q[1], q[2], q[3]);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(q[4], q[5], q[6], q[7]);
                 }
             }
 #pragma unroll
@@ -543,8 +550,9 @@ __global__ __launch_bounds__(256) void k_uphead_adjoint_brick(const float* __res
 // ---------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256) void k_uphead_dx(const bf16_t* __restrict__ D, const bf16_t* __restrict__ wc,
-                                                   const bf16_t* __restrict__ x, const float* __restrict__ coef, int B, int h,
-                                                   int w, int d, int C, bf16_t* __restrict__ dx) {
+                                                   const bf16_t* __restrict__ x, const float* __restrict__ coef,
+                                                   const float* __restrict__ gx, int B, int h, int w, int d, int C,
+                                                   bf16_t* __restrict__ dx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const long T = (long)B * h * w * d;
@@ -569,6 +577,10 @@ __global__ __launch_bounds__(256) void k_uphead_dx(const bf16_t* __restrict__ D,
         if (!live || c0 >= C) continue;
         f32x4 gram = fzero4();
         const bf16_t* xp = x + pp * C + c0;
+        if (gx) {                                                 // the forward's statistics pass kept U^T U x
+            const float4 q = *reinterpret_cast<const float4*>(gx + pp * C + c0);
+            gram[0] = q.x; gram[1] = q.y; gram[2] = q.z; gram[3] = q.w;
+        } else
 #pragma unroll
         for (int m0 = -1; m0 <= 1; ++m0) {
             const float g0 = gram_w(p0, m0, h);
@@ -716,13 +728,13 @@ extern "C" int mivp_uphead_nblk(int32_t B, int32_t h, int32_t w, int32_t d, int3
 }
 
 extern "C" int mivp_uphead_stats(const void* x, int32_t B, int32_t h, int32_t w, int32_t d, int32_t C, float* part,
-                                 mivp_stream_t stream) {
+                                 float* gx, mivp_stream_t stream) {
     int rc = uphead_checks(B, h, w, d, C, 1);
     if (rc) return rc;
     MIVP_REQUIRE(x && part);
     MIVP_REQUIRE((long)B * h * w * ((d + ST_SEG - 1) / ST_SEG) * (C / 8) < (1L << 31));     // 32-bit decode in the kernel
     hipLaunchKernelGGL(k_uphead_stats, dim3(mivp_uphead_nblk(B, h, w, d, C)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (int)B, (int)h, (int)w, (int)d, (int)C, part);
+                       (const bf16_t*)x, (int)B, (int)h, (int)w, (int)d, (int)C, part, gx);
     return mivp_check_launch("uphead_stats");
 }
 
@@ -782,8 +794,8 @@ extern "C" int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B
 
 /* dx [B,h,w,d,C] bf16 from D (row stride 64, columns >= 27*Cout zero), wc bf16 [16*ceil(C/16)][64] = conv weight as
  * [c][tap*Cout + co], coef f32 [4][C] = (scale | S1/N | rstd*S2/N | mean); see k_uphead_dx. */
-extern "C" int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, int32_t B, int32_t h, int32_t w,
-                              int32_t d, int32_t C, void* dx, mivp_stream_t stream) {
+extern "C" int mivp_uphead_dx(const void* D, const void* wc, const void* x, const float* coef, const float* gx, int32_t B,
+                              int32_t h, int32_t w, int32_t d, int32_t C, void* dx, mivp_stream_t stream) {
     int rc = uphead_checks(B, h, w, d, C, 1);
     if (rc) return rc;
     MIVP_REQUIRE(D && wc && x && coef && dx);
@@ -791,7 +803,7 @@ extern "C" int mivp_uphead_dx(const void* D, const void* wc, const void* x, cons
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
 #define UP_DX(K) hipLaunchKernelGGL((k_uphead_dx<K>), dim3(grid), dim3(256), 0, st, (const bf16_t*)D, (const bf16_t*)wc,      \
-                                    (const bf16_t*)x, coef, (int)B, (int)h, (int)w, (int)d, (int)C, (bf16_t*)dx)
+                                    (const bf16_t*)x, coef, gx, (int)B, (int)h, (int)w, (int)d, (int)C, (bf16_t*)dx)
     switch ((C + 15) / 16) {
         case 1: UP_DX(1); break;
         case 2: UP_DX(2); break;

@@ -413,16 +413,21 @@ class _UpHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bn_w, bn_b, conv_w, conv_b, bn):
+        gx = None
         if bn.training:
-            scale, shift, mean_rstd = ops.uphead_batch_stats(
+            keep_gx = bool(ctx.needs_input_grad[0])               # the backward w.r.t. x reuses U^T U x from this pass
+            res = ops.uphead_batch_stats(
                 x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
-                bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
+                bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, keep_gx)
+            scale, shift, mean_rstd = res[:3]
+            gx = res[3] if keep_gx else None
             bump_counter(bn.num_batches_tracked)
         else:
             scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
         cout = conv_w.shape[0]
         y = ops.uphead_forward(x, ops.uphead_fold(conv_w, scale, shift), conv_b, cout)
         ctx.save_for_backward(x, scale, shift, mean_rstd, conv_w)
+        ctx.gx = gx
         ctx.cout = cout
         ctx.training = bn.training
         return y
@@ -436,7 +441,8 @@ class _UpHeadFn(torch.autograd.Function):
         else:
             G, S = ops.uphead_gs(x, dy, ctx.cout, raw=True)
         dw, db, dgamma, dbeta = ops.head_grads_fused(G, S, conv_w, scale, shift, mean_rstd)
-        dx = ops.uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, ctx.training) if g[0] else None
+        dx = ops.uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, ctx.training, ctx.gx) if g[0] else None
+        ctx.gx = None
         return (dx, dgamma if g[1] else None, dbeta if g[2] else None, dw if g[3] else None, db if g[4] else None, None)
 
 

@@ -161,14 +161,17 @@ def uphead_supported(cin: int, cout: int) -> bool:
     return cin % 8 == 0 and cin + 1 <= 64 and 1 <= cout <= 2
 
 
-def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.1):
-    """Training-mode BatchNorm statistics of upsample_x2(x) computed from x: (scale, shift, mean_rstd)."""
+def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None, momentum=0.1, keep_gx=False):
+    """Training-mode BatchNorm statistics of upsample_x2(x) computed from x: (scale, shift, mean_rstd).
+    ``keep_gx`` appends gx f32 [B,h,w,d,C] = U^T U x (the pass forms it anyway; uphead_dx reads it back)."""
     B, h, w, d, Cc = x.shape
+    gx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if keep_gx else None
     nblk = L.lib().mivp_uphead_nblk(C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(Cc))
     part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
     L.call("mivp_uphead_stats", L.ptr(x), C.c_int32(B), C.c_int32(h), C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(part),
-           L.stream())
-    return bn_finalize(part, nblk, Cc, 8 * B * h * w * d, weight, bias, eps, running_mean, running_var, momentum)
+           L.ptr(gx), L.stream())
+    out = bn_finalize(part, nblk, Cc, 8 * B * h * w * d, weight, bias, eps, running_mean, running_var, momentum)
+    return (*out, gx) if keep_gx else out
 
 
 def uphead_fold(conv_w, scale, shift):
@@ -226,8 +229,9 @@ def head_grads_fused(G, S, conv_w, scale, shift, mean_rstd):
     return dW, db, dgamma, dbeta
 
 
-def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training):
-    """Gradient w.r.t. the low-res x through upsample -> BatchNorm -> conv (see k_uphead_dx)."""
+def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training, gx=None):
+    """Gradient w.r.t. the low-res x through upsample -> BatchNorm -> conv (see k_uphead_dx); ``gx`` from
+    uphead_batch_stats(keep_gx=True) spares the kernel its 27-point gather."""
     B, h, w, d, Cc = x.shape
     cout = conv_w.shape[0]
     wc = torch.empty((round_up(Cc, 16), 64), dtype=BF16, device=x.device)
@@ -236,7 +240,7 @@ def uphead_dx(x, D, conv_w, scale, mean_rstd, dgamma, dbeta, training):
            L.ptr(dgamma if training else None), L.ptr(dbeta if training else None), C.c_double(8.0 * B * h * w * d),
            C.c_int32(1 if training else 0), C.c_int32(cout), C.c_int32(Cc), L.ptr(wc), L.ptr(coef), L.stream())
     dx = torch.empty_like(x)
-    L.call("mivp_uphead_dx", L.ptr(D), L.ptr(wc), L.ptr(x), L.ptr(coef), C.c_int32(B), C.c_int32(h),
+    L.call("mivp_uphead_dx", L.ptr(D), L.ptr(wc), L.ptr(x), L.ptr(coef), L.ptr(gx), C.c_int32(B), C.c_int32(h),
            C.c_int32(w), C.c_int32(d), C.c_int32(Cc), L.ptr(dx), L.stream())
     return dx
 
