@@ -133,7 +133,10 @@ extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const
     MIVP_REQUIRE(T < (1L << 31));                               // merge_token decodes in 32 bits
     const unsigned gx = (unsigned)((T + 63) / 64);
     const int n_tiles = (d->Cout + 15) / 16;
-    int ny = (int)((1024 + gx - 1) / gx);                    // aim at >= 1024 workgroups
+    // every workgroup repeats the gather + LayerNorm prologue of its 64 tokens, so split the output tiles only as far as
+    // ONE resident round of workgroups goes: 2 per CU for KS = 24 (221 VGPRs), 4 for KS = 12, 8 below
+    const long resident = 256L * (KS >= 24 ? 2 : KS >= 12 ? 4 : 8);
+    int ny = (int)(resident / gx);
     if (ny > n_tiles) ny = n_tiles;
     if (ny < 1) ny = 1;
     const dim3 grid(gx, (unsigned)ny);
