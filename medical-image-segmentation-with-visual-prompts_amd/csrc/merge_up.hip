@@ -342,6 +342,7 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
 // formed ONCE, tile by tile, and the tiles are split over gridDim.y (the deep stages have only a few dozen token
 // groups and hundreds of MFMAs per token).
 // ---------------------------------------------------------------------------------------------
+constexpr int MB_BATCH = 4;                                    // row pieces in flight per lane in the statistics pass
 template <int NS>
 __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const bf16_t* __restrict__ dy,
                                                          const bf16_t* __restrict__ x, const bf16_t* __restrict__ yfwd,
@@ -379,32 +380,41 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     }
     const float m1 = col_sum(s1) / (float)kC, m2 = col_sum(s2) / (float)kC;
 
-    auto load_x4 = [&](int c0, long& src_out) -> f32x4 {
-        f32x4 v = fzero4();
-        src_out = -1;
-        if (m.live && c0 < kC) {
-            const int part = c0 / C, ch = c0 - part * C;
-            const long src = merge_src(d, m, part);
-            if (src >= 0) {
-                const bf16x4 raw = ld4(x + src * C + ch);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (float)raw[j];
-                src_out = src * C + ch;
-            }
-        }
-        return v;
+    // Row statistics in ONE pass of 16-byte loads (sum and sum of squares in fp32; the rows are at most 1536 bf16 values
+    // of O(1) magnitude).  The loads are unconditional -- a dead piece reads offset 0 and is masked afterwards -- and go
+    // out MB_BATCH at a time: with a branch per piece they serialised into one memory round trip each, which was most of this
+    // kernel's time at the deep stages.
+    auto piece_off = [&](int c0, bool& ok) -> long {             // element offset of concat channel c0 of this lane's token
+        const int cc = c0 < kC ? c0 : 0;
+        const int part = cc / C, ch = cc - part * C;
+        const long src = merge_src(d, m, part);
+        ok = m.live && c0 < kC && src >= 0;
+        return ok ? src * C + ch : 0;
     };
-    float sum = 0.f;
-    for (int ct = 0; ct < n_ct; ++ct) { long so; const f32x4 v = load_x4(16 * ct + 4 * g, so); sum += v[0] + v[1] + v[2] + v[3]; }
-    const float mean = col_sum(sum) / (float)kC;
-    float var = 0.f;
-    for (int ct = 0; ct < n_ct; ++ct) {
-        long so;
-        const int c0 = 16 * ct + 4 * g;
-        const f32x4 v = load_x4(c0, so);
-        if (c0 < kC) for (int j = 0; j < 4; ++j) { const float dv = v[j] - mean; var += dv * dv; }
+    float sum = 0.f, sq = 0.f;
+    const int n_k8 = (kC + 31) / 32;
+    for (int s0 = 0; s0 < n_k8; s0 += MB_BATCH) {
+        bf16x8 raw[MB_BATCH];
+        bool ok[MB_BATCH];
+#pragma unroll
+        for (int u = 0; u < MB_BATCH; ++u) {
+            const int c = 32 * (s0 + u) + 8 * g;
+            const long off = piece_off(s0 + u < n_k8 ? c : kC, ok[u]);
+            raw[u] = ld8(x + off);
+        }
+#pragma unroll
+        for (int u = 0; u < MB_BATCH; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = ok[u] ? (float)raw[u][i] : 0.f;
+                sum += v;
+                sq += v * v;
+            }
     }
-    const float rstd = rsqrtf(col_sum(var) / (float)kC + d.ln_eps);
+    const float mean = col_sum(sum) / (float)kC;
+    float var = col_sum(sq) / (float)kC - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + d.ln_eps);
 
     const int per_y = (n_ct + gridDim.y - 1) / gridDim.y;
     const int ct_lo = blockIdx.y * per_y, ct_hi = (ct_lo + per_y) < n_ct ? (ct_lo + per_y) : n_ct;
@@ -416,14 +426,19 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     for (int ct = ct_lo; ct < ct_hi; ++ct) {
         f32x4 gy = fzero4();
         const int cur = (ct - ct_lo) & 1;
+        const int c0 = 16 * ct + 4 * g;
+        bool okx;
+        const long xo = piece_off(c0, okx);
+        const bf16x4 xraw = ld4(x + xo);                          // in flight under the MFMAs
+        const long so = okx ? xo : -1;
         if (ct + 1 < ct_hi) ws.fetch(w_t, Cout, 16 * (ct + 1), kC, Cout);
 #pragma unroll
         for (int s = 0; s < NS; ++s) gy = mfma16(WS::frag8(wsm, cur, s, r, 8 * g), dyb[s], gy);
         if (ct + 1 < ct_hi) ws.store(wsm, cur ^ 1);
         __syncthreads();
-        const int c0 = 16 * ct + 4 * g;
-        long so;
-        const f32x4 v = load_x4(c0, so);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = okx ? (float)xraw[j] : 0.f;
         if (wg_dn && m.live && c0 < kC) {
             st4(wg_dn + t * kC + c0, pack4(gy));
             st4(wg_x + t * kC + c0, pack4(v));
@@ -449,7 +464,7 @@ extern "C" int mivp_patch_merge_bwd(const MivpMergeDesc* d, const void* dy, cons
     const unsigned gx = (unsigned)((T + 63) / 64);
     const int kC = (d->merge_last ? 8 : 4) * d->C, n_ct = (kC + 15) / 16;
     int ny = (int)((1024 + gx - 1) / gx);
-    if (ny > n_ct) ny = n_ct;
+    if (ny > n_ct / 3) ny = n_ct / 3;                           // at least three tiles behind each statistics prologue
     if (ny < 1) ny = 1;
     const dim3 grid(gx, (unsigned)ny);
     hipStream_t st = (hipStream_t)stream;
