@@ -295,6 +295,73 @@ __global__ __launch_bounds__(256) void k_upcat_bwd_x(MivpUpcatDesc d, const bf16
     }
 }
 
+// align_corners == 0 form of k_upcat_bwd_x: an input voxel is touched by at most the four outputs 2i-1 .. 2i+2 per axis
+// (one output for a scale-1 axis).  Candidate indices and weights are static arrays, every load is unconditional (a
+// candidate outside the cropped output reads a clamped index with weight 0): the 64 loads of an item are independent
+// instead of 64 serial round trips behind dynamically indexed candidate lists.
+__global__ __launch_bounds__(256) void k_upcat_bwd_x4(MivpUpcatDesc d, const bf16_t* __restrict__ dy,
+                                                      bf16_t* __restrict__ dx) {
+    const int Ct = d.Cx + d.Cs, Gx = d.Cx / 8;
+    const long ivol = (long)d.idims[0] * d.idims[1] * d.idims[2];
+    const long items = (long)d.B * ivol * Gx;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (long it = gtid; it < items; it += stride) {
+        const unsigned vox = (unsigned)it / (unsigned)Gx;     // host checks items < 2^31: 32-bit decode
+        const int cg = (int)((unsigned)it - vox * (unsigned)Gx);
+        const unsigned b = vox / (unsigned)ivol;
+        unsigned rem = vox - b * (unsigned)ivol;
+        const unsigned i12 = (unsigned)(d.idims[1] * d.idims[2]);
+        int ic[3];
+        ic[0] = (int)(rem / i12);
+        rem -= (unsigned)ic[0] * i12;
+        ic[1] = (int)(rem / (unsigned)d.idims[2]);
+        ic[2] = (int)(rem - (unsigned)ic[1] * (unsigned)d.idims[2]);
+        int co[3][4];
+        float cw[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool two = d.scale[a] == 2;
+                const int o = two ? 2 * ic[a] - 1 + k : ic[a];
+                const bool valid = (two || k == 0) && o >= 0 && o < d.odims[a];
+                float wgt = 0.f;
+                if (valid) {
+                    const Lerp l = lerp_axis(o, d.scale[a], d.idims[a], 0);
+                    wgt = (l.i0 == ic[a] ? l.w0 : 0.f) + (l.i1 == ic[a] ? l.w1 : 0.f);
+                }
+                co[a][k] = valid ? o : 0;
+                cw[a][k] = wgt;
+            }
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const bf16_t* base = dy + cg * 8;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float w01 = cw[0][a] * cw[1][bb];
+                const long row = (((long)b * d.odims[0] + co[0][a]) * d.odims[1] + co[1][bb]) * d.odims[2];
+                bf16x8 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ld8(base + (row + co[2][c]) * Ct);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float wgt = w01 * cw[2][c];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += wgt * (float)v[c][i];
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)acc[i];
+        st8(dx + (long)vox * d.Cx + cg * 8, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_upcat_bwd_skip(MivpUpcatDesc d, const bf16_t* __restrict__ dy,
                                                         bf16_t* __restrict__ dskip) {
     const int Ct = d.Cx + d.Cs, Gs = d.Cs / 8;
@@ -317,7 +384,10 @@ extern "C" int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, 
         const long items = (long)d->B * d->idims[0] * d->idims[1] * d->idims[2] * (d->Cx / 8);
         MIVP_REQUIRE(items < (1L << 31));                        // 32-bit decode in the kernel
         const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
-        hipLaunchKernelGGL(k_upcat_bwd_x, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy, (bf16_t*)dx);
+        if (d->align_corners)
+            hipLaunchKernelGGL(k_upcat_bwd_x, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy, (bf16_t*)dx);
+        else
+            hipLaunchKernelGGL(k_upcat_bwd_x4, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)dy, (bf16_t*)dx);
         int rc = mivp_check_launch("upcat_bwd_x");
         if (rc) return rc;
     }
