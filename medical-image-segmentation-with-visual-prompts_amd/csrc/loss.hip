@@ -160,7 +160,15 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
         const int k = kk < 3 * C ? kk : 3 * LOSS_MAXC;
         const int i = b * K + k;
         double s = 0.0;
-        for (int j = lane; j < blocks_per_b; j += 64) s += (double)part[((long)b * blocks_per_b + j) * K + k];
+        int j = lane;
+        for (; j + 64 * 7 < blocks_per_b; j += 64 * 8) {         // eight independent loads per round trip, same order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[((long)b * blocks_per_b + j + 64 * u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; j < blocks_per_b; j += 64) s += (double)part[((long)b * blocks_per_b + j) * K + k];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) stats[i] = (float)s;
     }

@@ -172,7 +172,15 @@ __global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ pa
                                                     float* __restrict__ mean_rstd) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = lane; i < nblk; i += 64) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
+    int i = lane;
+    for (; i + 64 * 7 < nblk; i += 64 * 8) {                     // 16 independent loads per round trip, same summation order
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v1[u] = part[(long)(i + 64 * u) * 2 * C + c]; v2[u] = part[(long)(i + 64 * u) * 2 * C + C + c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+    }
+    for (; i < nblk; i += 64) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if (lane != 0) return;
     const double mean = s1 / count;

@@ -68,6 +68,14 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ 
     float a0 = 0.f, a1 = 0.f;
     if (rr < rows) {
         long i = slice;
+        // eight independent loads per round trip, added in the same order as the two-at-a-time tail loop (same bits)
+        for (; i + 224 < n; i += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(i + 32 * u) * rows + rr];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += v[u]; a1 += v[u + 1]; }
+        }
         for (; i + 32 < n; i += 64) { a0 += in[i * rows + rr]; a1 += in[(i + 32) * rows + rr]; }
         if (i < n) a0 += in[i * rows + rr];
     }
@@ -158,6 +166,14 @@ __global__ __launch_bounds__(1024) void k_reduce_rows_multi(ReduceSegs sg, int n
     float a0 = 0.f, a1 = 0.f;
     if (rr < rows) {
         long i = slice;
+        // eight independent loads per round trip, added in the same order as the two-at-a-time tail loop (same bits)
+        for (; i + 224 < n; i += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(i + 32 * u) * rows + rr];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += v[u]; a1 += v[u + 1]; }
+        }
         for (; i + 32 < n; i += 64) { a0 += in[i * rows + rr]; a1 += in[(i + 32) * rows + rr]; }
         if (i < n) a0 += in[i * rows + rr];
     }
