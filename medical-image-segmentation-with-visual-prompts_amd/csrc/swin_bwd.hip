@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
 // gradient of the prompt-token bias score).
 // ---------------------------------------------------------------------------------------------
 template <int DKS, int DVT, int KPW, int NW, bool AUG, bool DROP, bool MASKED>
-__global__ __launch_bounds__(64 * NW, (DKS == 1 && !AUG && !DROP) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
+__global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 4 : 2) void k_win_attn_bwd_dkv(MivpSwinDesc d, int chunk_tiles, int kt0,
                                                           const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kp,
                                                           const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
