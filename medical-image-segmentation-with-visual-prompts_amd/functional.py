@@ -215,6 +215,19 @@ def token_scores(pe, n_prompt):
     return pe.token_scores(n_prompt)
 
 
+def content_tables(pe):
+    """RelativePE.content_tables() -- three [heads, 2w-1] tables -- through the same fused kernels (one launch per table
+    and direction; the torch form is a matmul + a scaling forward and two matmuls + a scaling backward per table, ~220
+    tiny launches per all-weights step)."""
+    heads, e = pe.weights_content_h.shape
+    rows = max(getattr(pe, f"enc_content_{a}").shape[0] for a in "hwd")
+    if not pe.weights_content_h.is_cuda or ((heads + rows) * e + heads * rows) * 4 > 64 * 1024:
+        return pe.content_tables()
+    s3 = float(pe.scale) / 3.0
+    return tuple(_TokenScoresFn.apply(getattr(pe, f"weights_content_{a}"), getattr(pe, f"enc_content_{a}"),
+                                      int(getattr(pe, f"enc_content_{a}").shape[0]), s3) for a in "hwd")
+
+
 def swin_block(block, x, prompt: Optional[torch.Tensor]):
     pe, attn = block.pe, block.attn
     body = [block.attn_norm.weight, block.attn_norm.bias, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
@@ -243,7 +256,7 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
         seeds = torch.randint(0, 2 ** 31 - 1, (2,))
         dropout = (p_attn, p_proj, int(seeds[0]), int(seeds[1]))
     if train_w:
-        t_h, t_w, t_d = pe.content_tables()       # same for the content tables [heads, 2w-1]
+        t_h, t_w, t_d = content_tables(pe)        # same for the content tables [heads, 2w-1]
         return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, dropout,
                                        *body)
     return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size, dropout)
