@@ -203,12 +203,15 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
     const float w00 = lh.w0 * lw.w0, w01 = lh.w0 * lw.w1, w10 = lh.w1 * lw.w0, w11 = lh.w1 * lw.w1;
     bf16_t* yrow = y + (long)row * OD * Ct;
     const bf16_t* srow = skip ? skip + (long)row * OD * d.Cs : nullptr;
+    // items ordered interpolation first, skip copies last: waves are homogeneous (a mixed wave runs both paths)
+    const int nI = OD * Gx, Gs = G - Gx;
     for (int it = threadIdx.x; it < OD * G; it += 256) {
-        const int od = it / G, cg = it - od * G;
-        if (cg >= Gx) {
-            st8(yrow + od * Ct + cg * 8, ld8(srow + od * d.Cs + (cg - Gx) * 8));
+        if (it >= nI) {
+            const int j = it - nI, od = j / Gs, cg = j - od * Gs;
+            st8(yrow + od * Ct + (Gx + cg) * 8, ld8(srow + od * d.Cs + cg * 8));
             continue;
         }
+        const int od = it / Gx, cg = it - od * Gx;
         const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2], d.align_corners);
         const int o0 = ld.i0 * d.Cx + cg * 8, o1 = ld.i1 * d.Cx + cg * 8;
         const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
