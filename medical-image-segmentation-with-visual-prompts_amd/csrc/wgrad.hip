@@ -97,21 +97,38 @@ MIVP_DEV void tokpos_advance(TokPos& s, int step, const MivpOperandDesc& oa, con
     }
 }
 
-MIVP_DEV bf16x4 piece_load(const MivpOperandDesc& o, const PieceAddr& p, const bf16_t* __restrict__ base, const TokPos& s, long T,
-                           int C) {
+// a column piece is 4 channels (8-byte load) or, when every column offset and row stride involved is a multiple of 8
+// (P8, decided on the host), 8 channels through one 16-byte load: half the loads, address updates and LDS stores
+template <bool P8> struct Piece { typedef bf16x4 type; };
+template <> struct Piece<true> { typedef bf16x8 type; };
+template <bool P8> MIVP_DEV typename Piece<P8>::type piece_zero();
+template <> MIVP_DEV bf16x4 piece_zero<false>() { return zero4(); }
+template <> MIVP_DEV bf16x8 piece_zero<true>() { return zero8(); }
+template <bool P8> MIVP_DEV typename Piece<P8>::type piece_ld(const bf16_t* p);
+template <> MIVP_DEV bf16x4 piece_ld<false>(const bf16_t* p) { return ld4(p); }
+template <> MIVP_DEV bf16x8 piece_ld<true>(const bf16_t* p) { return ld8(p); }
+
+template <bool P8>
+MIVP_DEV typename Piece<P8>::type piece_load(const MivpOperandDesc& o, const PieceAddr& p, const bf16_t* __restrict__ base,
+                                             const TokPos& s, long T, int C) {
     const long t = s.t;
-    if (!p.col_ok || t >= T) return zero4();
-    if (o.mode == 0) return ld4(base + t * o.ld + p.col_off);
-    if (o.mode == 1) return ld4(base + (s.win * (C / o.hd)) * o.rows * o.hd + (long)s.n * o.hd + p.col_off);
+    if (!p.col_ok || t >= T) return piece_zero<P8>();
+    if (o.mode == 0) return piece_ld<P8>(base + t * o.ld + p.col_off);
+    if (o.mode == 1) return piece_ld<P8>(base + (s.win * (C / o.hd)) * o.rows * o.hd + (long)s.n * o.hd + p.col_off);
     const int D = o.dims[2], W = o.dims[1], H = o.dims[0];
     const int hh = s.h + p.dh, ww = s.w + p.dw, dd = s.d + p.dd;
-    if ((unsigned)hh >= (unsigned)H || (unsigned)ww >= (unsigned)W || (unsigned)dd >= (unsigned)D) return zero4();
-    return ld4(base + (t + ((long)p.dh * W + p.dw) * D + p.dd) * o.ld + p.col_off);
+    if ((unsigned)hh >= (unsigned)H || (unsigned)ww >= (unsigned)W || (unsigned)dd >= (unsigned)D) return piece_zero<P8>();
+    return piece_ld<P8>(base + (t + ((long)p.dh * W + p.dw) * D + p.dd) * o.ld + p.col_off);
 }
 
 
+template <bool P8>
 __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                  float* __restrict__ part, int chunks_per_split) {
+    constexpr int PW = P8 ? 8 : 4;                            // channels per piece
+    constexpr int PPR = TN_BLK / PW;                          // pieces per 64-channel row: 16 or 8
+    constexpr int RPP = 256 / PPR;                            // token rows covered per pass: 16 or 32
+    constexpr int NP = TN_TOK / RPP;                          // passes per 128-token chunk: 8 or 4
     __shared__ __attribute__((aligned(16))) char smem[2 * TN_TOK * TN_BLK * 2];   // A image, B image: 16 KB each
     char* As = smem;
     char* Bs = smem + TN_TOK * TN_BLK * 2;
@@ -120,9 +137,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
     // stream it in step, so the operands come out of L2 (with the split index fastest every 64-column block of a conv
     // weight gradient re-read dy and its tap-displaced x from HBM: 4.0 ms for the 144->48 conv at 48^3, 41 TFLOP/s)
     const int m0 = blockIdx.y * TN_BLK, n0 = blockIdx.x * TN_BLK;
-    const int cp = tid & 15, r0 = tid >> 4;                    // column piece (4 channels), first row
-    const PieceAddr pa = piece_setup(d.a, m0 + 4 * cp, d.M);
-    const PieceAddr pb = piece_setup(d.b, n0 + 4 * cp, d.N);
+    const int cp = tid % PPR, r0 = tid / PPR;                  // column piece (PW channels), first row
+    const PieceAddr pa = piece_setup(d.a, m0 + PW * cp, d.M);
+    const PieceAddr pb = piece_setup(d.b, n0 + PW * cp, d.N);
 
     const long nchunks = (d.T + TN_TOK - 1) / TN_TOK;
     const long c_lo = (long)blockIdx.z * chunks_per_split;
@@ -135,25 +152,26 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MivpGemmTnDesc d, const bf16_t*
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fzero4();
 
-    bf16x4 ra[8], rb[8];
-    TokPos pos;                                               // token c_lo * 128 + r0, then +16 per piece, chunk after chunk
+    typedef typename Piece<P8>::type piece_t;
+    piece_t ra[NP], rb[NP];
+    TokPos pos;                                               // token c_lo * 128 + r0, then +RPP per piece, chunk after chunk
     tokpos_init(pos, c_lo * TN_TOK + r0, d.a, d.b);
     auto fetch = [&](long) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ra[i] = piece_load(d.a, pa, a, pos, d.T, d.M);
-            rb[i] = piece_load(d.b, pb, b, pos, d.T, d.N);
-            tokpos_advance(pos, 16, d.a, d.b);
+        for (int i = 0; i < NP; ++i) {
+            ra[i] = piece_load<P8>(d.a, pa, a, pos, d.T, d.M);
+            rb[i] = piece_load<P8>(d.b, pb, b, pos, d.T, d.N);
+            tokpos_advance(pos, RPP, d.a, d.b);
         }
     };
-    // where this thread's pieces go: token row r0 + 16 i, channels 4cp .. 4cp+3
+    // where this thread's pieces go: token row r0 + RPP i, channels PW cp .. PW cp + PW - 1 (16-channel block PW cp / 16)
     auto stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = r0 + 16 * i;
-            const int off = blk_off(row >> 2, cp >> 2) + (row & 3) * 32 + (cp & 3) * 8;
-            *reinterpret_cast<bf16x4*>(As + off) = ra[i];
-            *reinterpret_cast<bf16x4*>(Bs + off) = rb[i];
+        for (int i = 0; i < NP; ++i) {
+            const int row = r0 + RPP * i;
+            const int off = blk_off(row >> 2, (PW * cp) >> 4) + (row & 3) * 32 + ((PW * cp) & 15) * 2;
+            *reinterpret_cast<piece_t*>(As + off) = ra[i];
+            *reinterpret_cast<piece_t*>(Bs + off) = rb[i];
         }
     };
     // transposed fragment of output tile `ct` for this wave's 32 tokens: lane (r, g) gets tokens 8g..8g+7 of
@@ -246,6 +264,14 @@ int tn_splits(const MivpGemmTnDesc* d, int* chunks_per_split) {
     return (int)((nchunks + *chunks_per_split - 1) / *chunks_per_split);
 }
 
+// every column offset and row stride of the operand is a multiple of 8 elements: 16-byte pieces are legal
+int operand_p8(const MivpOperandDesc& o, int C, const void* base) {
+    if (C % 8 || ((uintptr_t)base & 15)) return 0;
+    if (o.mode == 0) return o.ld % 8 == 0;
+    if (o.mode == 1) return o.hd % 8 == 0;
+    return o.cin % 8 == 0 && o.ld % 8 == 0;
+}
+
 int check_operand(const MivpOperandDesc& o, int C) {
     if (o.mode == 0) return o.ld >= C && o.ld % 4 == 0;
     if (o.mode == 1) return o.hd > 0 && o.hd % 4 == 0 && C % o.hd == 0 && o.rows > 0;
@@ -272,8 +298,12 @@ extern "C" int mivp_gemm_tn(const MivpGemmTnDesc* d, const void* a, const void* 
     const int splits = tn_splits(d, &cps);
     MIVP_REQUIRE(ws_bytes >= (size_t)splits * d->M * d->N * sizeof(float));
     const dim3 grid((d->N + TN_BLK - 1) / TN_BLK, (d->M + TN_BLK - 1) / TN_BLK, splits);
-    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)a, (const bf16_t*)b,
-                       (float*)workspace, cps);
+    if (operand_p8(d->a, d->M, a) && operand_p8(d->b, d->N, b))
+        hipLaunchKernelGGL(k_gemm_tn<true>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)a, (const bf16_t*)b,
+                           (float*)workspace, cps);
+    else
+        hipLaunchKernelGGL(k_gemm_tn<false>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)a, (const bf16_t*)b,
+                           (float*)workspace, cps);
     const long total = (long)d->M * d->N;
     int slices = 1;
     while (slices < splits && slices < 32) slices *= 2;
