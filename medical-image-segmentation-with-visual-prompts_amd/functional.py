@@ -378,7 +378,9 @@ class _BnActConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean_rstd = ctx.saved_tensors
-        training, lrelu, (wd, cpad), cout, cin = ctx.meta
+        training, lrelu, wd_pack, cout, cin = ctx.meta
+        wd, cpad = wd_pack[0], wd_pack[1]
+        wd16 = wd_pack[2] if len(wd_pack) > 2 else None
         need_x, need_bw, need_bb, need_cw, need_cb = ctx.needs_input_grad[:5]
         dy_p = dy
         if dy.dtype != BF16 or dy.shape[-1] != cpad or not dy.is_contiguous():
@@ -387,7 +389,12 @@ class _BnActConvFn(torch.autograd.Function):
         dx = dgamma = dbeta = dw = db = None
         rows_ok = (not lrelu) and ops.conv3d_wgrad_rows_supported(cin, cout, x.shape[3])
         if need_x:
-            dz = ops.conv3d(dy_p, wd, None, cin)            # gradient w.r.t. the conv operand act(BN(x))
+            if wd16 is not None and ops.halo_brick(x.shape[0], tuple(x.shape[1:4]), cin):
+                dy16 = torch.zeros(dy.shape[:-1] + (16,), dtype=BF16, device=dy.device)     # one 16-channel halo chunk
+                dy16[..., :cout] = dy
+                dz = ops.conv3d(dy16, wd16, None, cin)
+            else:
+                dz = ops.conv3d(dy_p, wd, None, cin)        # gradient w.r.t. the conv operand act(BN(x))
             if training:
                 dx, dgamma, dbeta = ops.bn_backward(x, dz, scale, shift, mean_rstd, lrelu)
             else:
@@ -413,7 +420,8 @@ def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
     key = key or "bn_conv"
 
     def build():
-        return ops.pack_conv_weight(conv.weight), ops.pack_conv_weight_dgrad(conv.weight)
+        wd, cpad = ops.pack_conv_weight_dgrad(conv.weight)
+        return ops.pack_conv_weight(conv.weight), (wd, cpad, ops.pack_conv_weight_dgrad16(conv.weight))
 
     wp, wd = owner._wcache.get(key, [conv.weight], build)
     return _BnActConvFn.apply(x, bn.weight, bn.bias, conv.weight, conv.bias, bn, wp, wd, lrelu, out_f32)

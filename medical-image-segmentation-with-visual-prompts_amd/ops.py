@@ -48,6 +48,16 @@ def pack_conv_weight_dgrad(w: torch.Tensor) -> Tuple[torch.Tensor, int]:
     return pack_conv_weight(wf, cin_pad=cpad), cpad
 
 
+def pack_conv_weight_dgrad16(w: torch.Tensor):
+    """The same data-gradient pack for dy padded to 16 channels, or None when pack_conv_weight_dgrad already is one.  The
+    halo-brick kernel stages 16-channel chunks: a segmentation head's 2-5 class gradient padded to 8 channels falls to the
+    im2col kernel (675 us at 4 x 96^3), padded to 16 it runs as one halo chunk."""
+    if round_up(w.shape[0], 8) >= 16:
+        return None
+    wf = w.detach().float().flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()
+    return pack_conv_weight(wf, cin_pad=16)
+
+
 def conv_desc(B, dims, cin, cout, affine, lrelu, residual, out_f32) -> L.ConvDesc:
     d = L.ConvDesc()
     d.B = B

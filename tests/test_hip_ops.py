@@ -34,6 +34,7 @@ def cf(t):       # channels-last device -> [B,C,H,W,D] float cpu
     (32, 36, (8, 16, 32), True),           # Cout not a multiple of 16
     (48, 144, (5, 9, 17), True),           # three output-channel groups (dgrad of the dec2 conv)
     (96, 96, (8, 8, 16), False),           # two groups
+    (16, 48, (9, 13, 21), False),          # one input chunk: the data gradient of a few-class head padded to 16 channels
 ])
 def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     """The halo-brick form (csrc/conv3d_halo.hip) against F.conv3d and against the im2col kernel on the same input."""

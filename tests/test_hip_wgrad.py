@@ -62,7 +62,8 @@ def test_gemm_tn_conv_taps(B, dims, cin, cout):
     assert rel_l2(out.view(cout, cin, 3, 3, 3).cpu(), w.grad.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,dims,lrelu", [(24, 16, (6, 6, 8), True), (48, 5, (2, 3, 96), False), (144, 48, (8, 8, 8), True)])
+@pytest.mark.parametrize("cin,cout,dims,lrelu", [(24, 16, (6, 6, 8), True), (48, 5, (2, 3, 96), False), (144, 48, (8, 8, 8), True),
+                                                (48, 5, (9, 13, 20), False)])     # 5-class head: data gradient as one 16-channel halo chunk
 def test_bn_act_conv_all_parameter_gradients(cin, cout, dims, lrelu):
     """BatchNorm -> (LeakyReLU) -> conv3x3x3 with every parameter trainable, through the autograd glue: the decoder's
     conv_concat stage and a 5-class head whose depth (96) is outside the one-pass head kernel's window.
