@@ -372,8 +372,9 @@ int mivp_uphead_fwd(const void* x, const void* wf, const float* bias, int32_t B,
  * sums of D give S = sum_{u in bounds} dy[u - tap][co]: the (G, S) of mivp_conv3d_wgrad_rows. */
 int mivp_uphead_adjoint(const float* dy, int32_t dy_stride, int32_t B, int32_t h, int32_t w, int32_t d, int32_t Cout,
                         void* D, int32_t ldD, mivp_stream_t stream);
-/* BatchNorm affine folded into the head conv (swin_unetr.py:229-237): wf bf16 [16*ceil(27*Cout/16)][64], row tap*Cout + co
- * = ( conv_w[co][c][tap] * scale[c]  for c < Cin | sum_c conv_w[co][c][tap] * shift[c] | 0 ... );  Cin < 64 */
+/* BatchNorm affine folded into the head conv (swin_unetr.py:229-237): wf bf16 [2][16*ceil(27*Cout/16)][64], row tap*Cout + co
+ * = ( conv_w[co][c][tap] * scale[c]  for c < Cin | sum_c conv_w[co][c][tap] * shift[c] | 0 ... );  Cin < 64.  Plane 0 holds
+ * the bf16 rounding of each value, plane 1 the bf16 rounding of the remainder (hi + lo pair, both fed to the MFMA). */
 int mivp_uphead_fold(const float* conv_w, const float* scale, const float* shift, int32_t Cout, int32_t Cin, void* wf,
                      mivp_stream_t stream);
 

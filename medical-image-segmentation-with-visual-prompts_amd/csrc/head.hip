@@ -21,7 +21,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 }
 
 // A operand, built once per call: row (tap, co) = tap*Cout + co ; column k < Cin: scale[k] * w[co][k][tap] ;
-// column k == Cin: sum_c shift[c] * w[co][c][tap] (multiplies the "ones" channel) ; bf16 [64][64]
+// column k == Cin: sum_c shift[c] * w[co][c][tap] (multiplies the "ones" channel) ; bf16 [2][64][64] (hi | lo parts)
 __global__ __launch_bounds__(64) void k_head_pack(MivpConvDesc d, const float* __restrict__ w, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, bf16_t* __restrict__ apack) {
     // one 64-lane block per row (tap, co); lane = column k
@@ -36,7 +36,10 @@ __global__ __launch_bounds__(64) void k_head_pack(MivpConvDesc d, const float* _
         if (k < Cin) val = scale[k] * w[((long)co * Cin + k) * 27 + tap];
         else if (k == Cin) val = part;
     }
-    apack[row * 64 + k] = (bf16_t)val;
+    // hi + lo pair: a single bf16 rounding of scale * w is a systematic 2^-9 error per weight (see csrc/uphead.hip)
+    const bf16_t hi = (bf16_t)val;
+    apack[row * 64 + k] = hi;
+    apack[(64 + row) * 64 + k] = (bf16_t)(val - (float)hi);
 }
 
 template <int KS>     // K steps of 32 covering Cin + 1 (the ones channel)
@@ -81,20 +84,21 @@ __global__ __launch_bounds__(256) void k_head_conv_fwd(MivpConvDesc d, const bf1
             xb[tt][s] = v;
         }
     }
-    bf16x8 af[4][KS];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+        bf16x8 af[KS], al[KS];                                     // weight rows of this tile: hi and lo parts
 #pragma unroll
-        for (int s = 0; s < KS; ++s) af[mt][s] = ld8(apack + (16 * mt + r) * 64 + 32 * s + 8 * g);
+        for (int s = 0; s < KS; ++s) {
+            af[s] = ld8(apack + (16 * mt + r) * 64 + 32 * s + 8 * g);
+            al[s] = ld8(apack + (64 + 16 * mt + r) * 64 + 32 * s + 8 * g);
+        }
+        const int row0 = 16 * mt + 4 * g;
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-        const int i = 16 * (wave + 4 * tt) + r;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int i = 16 * (wave + 4 * tt) + r;
             f32x4 acc = fzero4();
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma16(af[mt][s], xb[tt][s], acc);
-            const int row0 = 16 * mt + 4 * g;
+            for (int s = 0; s < KS; ++s) { acc = mfma16(af[s], xb[tt][s], acc); acc = mfma16(al[s], xb[tt][s], acc); }
             if (i < HALO && row0 < rows) {
                 f16x4 hv;
 #pragma unroll
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void k_head_conv_fwd(MivpConvDesc d, const bf1
     }
 }
 
-extern "C" size_t mivp_head_conv_ws(void) { return 64 * 64 * sizeof(bf16_t); }
+extern "C" size_t mivp_head_conv_ws(void) { return 2 * 64 * 64 * sizeof(bf16_t); }
 
 extern "C" int mivp_head_conv_fwd(const MivpConvDesc* d, const void* x, const float* w, const float* bias,
                                   const float* scale, const float* shift, void* workspace, float* y,
@@ -136,7 +140,7 @@ extern "C" int mivp_head_conv_fwd(const MivpConvDesc* d, const void* x, const fl
     const long nb = (long)d->B * ((d->dims[0] + HB_H - 1) / HB_H) * ((d->dims[1] + HB_W - 1) / HB_W) * ((d->dims[2] + HB_D - 1) / HB_D);
     const size_t lds = (size_t)HTILES * 16 * YROW;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_pack, dim3(64), dim3(64), 0, st, *d, w, scale, shift, (bf16_t*)workspace);
+    hipLaunchKernelGGL(k_head_pack, dim3(64), dim3(64), 0, st, *d, w, scale, shift, (bf16_t*)workspace);   // [2][64][64]
     int rc = mivp_check_launch("head_pack");
     if (rc) return rc;
     if (ks == 1) {

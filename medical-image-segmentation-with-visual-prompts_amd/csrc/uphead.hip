@@ -154,7 +154,12 @@ __global__ __launch_bounds__(256) void k_uphead_taps(const bf16_t* __restrict__ 
     for (int mt = 0; mt < MT; ++mt) {
         f32x4 acc = fzero4();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc = mfma16(ld8(wf + (long)(16 * mt + r) * 64 + 32 * s + 8 * g), xb[s], acc);
+        for (int s = 0; s < 2; ++s) {
+            // folded weights as a bf16 hi + lo pair: a single bf16 rounding of w * scale is a systematic 2^-9 error per
+            // weight (1.7e-3 of the logits, same sign for every voxel: it biased the arg-max near class boundaries)
+            acc = mfma16(ld8(wf + (long)(16 * mt + r) * 64 + 32 * s + 8 * g), xb[s], acc);
+            acc = mfma16(ld8(wf + (long)(16 * (MT + mt) + r) * 64 + 32 * s + 8 * g), xb[s], acc);
+        }
         if (live) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -620,7 +625,8 @@ static int uphead_checks(int B, int h, int w, int d, int C, int Cout) {
 // ~5 us each: 3 % of the downstream training step).
 // ---------------------------------------------------------------------------------------------
 namespace {
-// wf bf16 [mp][64]: row tap*Cout + co = ( w[co][c][tap] * scale[c] | sum_c w[co][c][tap] * shift[c] | 0 ... )
+// wf bf16 [2][mp][64]: row tap*Cout + co = ( w[co][c][tap] * scale[c] | sum_c w[co][c][tap] * shift[c] | 0 ... ) as a
+// hi + lo pair (hi = bf16(v), lo = bf16(v - hi)): plane 0 hi, plane 1 lo
 __global__ __launch_bounds__(256) void k_uphead_fold(const float* __restrict__ w, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int cout, int cin, int mp,
                                                      bf16_t* __restrict__ wf) {
@@ -636,7 +642,9 @@ __global__ __launch_bounds__(256) void k_uphead_fold(const float* __restrict__ w
         }
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == cin) v = part;
-        wf[row * 64 + lane] = (bf16_t)v;
+        const bf16_t hi = (bf16_t)v;
+        wf[row * 64 + lane] = hi;
+        wf[(mp + row) * 64 + lane] = (bf16_t)(v - (float)hi);
     }
 }
 

@@ -3,8 +3,9 @@
 Each fused stage is one ``torch.autograd.Function`` whose forward/backward launch kernels through
 ``ops`` / ``swin_ops``.  Activations between stages are channels-last bf16 tensors
 ``[B, H, W, D, C]``; parameters stay fp32 masters in the modules and are re-laid-out for the
-kernels by a small per-module cache that is refreshed when a parameter's version changes
-(optimizer step, ``load_state_dict``, ``.to()``).
+kernels by a small per-module cache that is refreshed when a parameter's version counter or storage
+changes (``load_state_dict``, ``.to()``, foreach optimizers) or when ANY optimizer has stepped since the
+copy was made (fused optimizers do not bump version counters: see ``WeightCache``).
 
 Every stage has two backward flavours, chosen at forward time from ``requires_grad`` of its parameters:
   * frozen parameters (``--training-mode downstream``: swin_unetr.py:33-40, segmentation.py:25-39): data
@@ -62,6 +63,29 @@ def flush_counters():
         _pending_counters.clear()
 
 
+# ``torch.optim.AdamW(fused=True)`` (and any other optimizer that updates parameters through an op without an
+# in-place-version bump) changes a parameter's values while ``p._version`` and ``p.data_ptr()`` stay the same, so the
+# version counter alone cannot tell a cache that its packed copies are stale.  Every optimizer step therefore advances a
+# process-wide epoch (a post-step hook registered for ALL torch optimizers, plus our own fused optimizer), and the stamp
+# of a parameter that can be stepped (``requires_grad``) carries it.  Frozen parameters keep version + pointer only, so the
+# frozen backbone of ``--training-mode downstream`` is packed once.
+_param_epoch = [0]
+
+
+def invalidate_weight_caches():
+    """Call after changing trainable parameters behind autograd's back (``p.data`` arithmetic through raw kernels)."""
+    _param_epoch[0] += 1
+
+
+def _optimizer_post_step(optimizer, args, kwargs):
+    _param_epoch[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
+
+_register_post_step(_optimizer_post_step)
+
+
 class WeightCache:
     """key -> kernel-ready tensors, rebuilt when any source parameter changed."""
 
@@ -70,7 +94,9 @@ class WeightCache:
 
     @staticmethod
     def _stamp(params):
-        return tuple((p._version, p.data_ptr(), str(p.device)) for p in params if p is not None)
+        ep = _param_epoch[0]
+        return tuple((p._version, p.data_ptr(), str(p.device), ep if p.requires_grad else -1)
+                     for p in params if p is not None)
 
     def get(self, key, params, builder):
         stamp = self._stamp(params)
@@ -81,6 +107,14 @@ class WeightCache:
             val = builder()
         self._store[key] = (stamp, val)
         return val
+
+
+def bn_momentum(bn) -> float:
+    """``momentum=None`` means a cumulative moving average in PyTorch (factor 1 / num_batches_tracked); the kernels take
+    one factor per call, so hand them that factor for THIS call (the counter is bumped after the forward)."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    return 1.0 / float(int(bn.num_batches_tracked) + 1)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -94,7 +128,7 @@ class _PatchEmbedFn(torch.autograd.Function):
         training = bn.training
         y, stats = ops.patch_embed(x, conv_w, conv_b, bn_w.detach().float().contiguous(),
                                    bn_b.detach().float().contiguous(), bn.eps, bn.running_mean, bn.running_var,
-                                   training=training, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                   training=training, momentum=bn_momentum(bn),
                                    return_stats=True)
         if training:
             bump_counter(bn.num_batches_tracked)
@@ -120,7 +154,7 @@ def patch_embed(owner, conv, bn, x):
     with torch.no_grad():
         y = ops.patch_embed(x.detach(), conv.weight, conv.bias, bn.weight.detach().float().contiguous(),
                             bn.bias.detach().float().contiguous(), bn.eps, bn.running_mean, bn.running_var,
-                            training=training, momentum=bn.momentum if bn.momentum is not None else 0.1)
+                            training=training, momentum=bn_momentum(bn))
         if training:
             bump_counter(bn.num_batches_tracked)
     return y
@@ -359,7 +393,7 @@ class _BnActConvFn(torch.autograd.Function):
         if bn.training:
             scale, shift, mean_rstd = ops.bn_batch_stats(
                 x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
-                bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
+                bn.running_mean, bn.running_var, bn_momentum(bn))
             bump_counter(bn.num_batches_tracked)
         else:
             scale, shift, mean_rstd = ops.bn_eval_affine(bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps)
@@ -439,7 +473,7 @@ class _UpHeadFn(torch.autograd.Function):
             keep_gx = bool(ctx.needs_input_grad[0])               # the backward w.r.t. x reuses U^T U x from this pass
             res = ops.uphead_batch_stats(
                 x, bn_w.detach().float().contiguous(), bn_b.detach().float().contiguous(), bn.eps,
-                bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, keep_gx)
+                bn.running_mean, bn.running_var, bn_momentum(bn), keep_gx)
             scale, shift, mean_rstd = res[:3]
             gx = res[3] if keep_gx else None
             bump_counter(bn.num_batches_tracked)

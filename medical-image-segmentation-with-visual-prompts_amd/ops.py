@@ -158,7 +158,7 @@ def head_conv(x, conv_w, conv_b, scale, shift):
     cout = conv_w.shape[0]
     d = conv_desc(B, (H, W, D), cin, cout, True, False, False, True)
     y = torch.empty((B, H, W, D, cout), dtype=torch.float32, device=x.device)
-    ws = torch.empty(64 * 64, dtype=BF16, device=x.device)
+    ws = torch.empty(int(L.lib().mivp_head_conv_ws()) // 2, dtype=BF16, device=x.device)     # the folded weight tile (hi | lo)
     L.call("mivp_head_conv_fwd", C.byref(d), L.ptr(x), L.ptr(conv_w.detach().float().contiguous()),
            L.ptr(conv_b.detach().float().contiguous()), L.ptr(scale), L.ptr(shift), L.ptr(ws), L.ptr(y), L.stream())
     return y
@@ -185,9 +185,10 @@ def uphead_batch_stats(x, weight, bias, eps, running_mean=None, running_var=None
 
 
 def uphead_fold(conv_w, scale, shift):
-    """BatchNorm affine folded into the head conv: bf16 [Mp][64], row tap*Cout + co = (w*scale | sum_c w*shift | 0)."""
+    """BatchNorm affine folded into the head conv: bf16 [2][Mp][64] (hi | lo halves of the f32 value), row tap*Cout + co =
+    (w*scale | sum_c w*shift | 0)."""
     cout, cin = conv_w.shape[0], conv_w.shape[1]
-    wf = torch.empty((round_up(27 * cout, 16), 64), dtype=BF16, device=conv_w.device)
+    wf = torch.empty((2, round_up(27 * cout, 16), 64), dtype=BF16, device=conv_w.device)
     L.call("mivp_uphead_fold", L.ptr(conv_w.detach().float().contiguous()), L.ptr(scale), L.ptr(shift), C.c_int32(cout),
            C.c_int32(cin), L.ptr(wf), L.stream())
     return wf

@@ -19,6 +19,25 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+LOG2E = 1.4426950408889634
+
+
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def r16(t: Tensor) -> Tensor:
+    """Round to bf16 and back, with a straight-through gradient.  Used only by the ``emulate_bf16`` options below:
+    the fp32 arithmetic of the reference with a rounding at every point where the HIP path STORES a bf16 value
+    (DESIGN.md section 2), so that a parity test measures kernel arithmetic instead of the storage format."""
+    return _RoundBf16.apply(t)
+
 
 # ----------------------------------------------------------------------------
 # geometry
@@ -81,7 +100,7 @@ class BlockGeometry:
 # relative position bias  (a9)
 # ----------------------------------------------------------------------------
 def rel_pos_bias(sd: Dict[str, Tensor], prefix: str, window: Sequence[int], n_prompt: int,
-                 embed_dim: int) -> Tensor:
+                 embed_dim: int, emulate_bf16: bool = False) -> Tensor:
     """Separable learned relative-position bias -> ``[heads, N, N + n_prompt]``.
 
     Follows multi_head_attention/relative_positional_encoding.py:99-142.
@@ -94,6 +113,10 @@ def rel_pos_bias(sd: Dict[str, Tensor], prefix: str, window: Sequence[int], n_pr
 
     Restated as a Toeplitz gather from per-axis ``[heads, 2w-1]`` tables instead
     of the reference's embedding gather + einsum.
+
+    ``emulate_bf16``: the HIP path carries the bias as extra bf16 columns of K' in log2 units (one column per query
+    slot coordinate: ``Th + c | Tw | Td - c`` with ``c = Td`` at query coordinate ``w2-1``, whose own column is dropped);
+    each of the three summands is rounded to bf16 after the multiplication by log2(e), as is the prompt-token score.
     """
     scale = embed_dim ** -0.5
     w = [int(v) for v in window]
@@ -106,6 +129,21 @@ def rel_pos_bias(sd: Dict[str, Tensor], prefix: str, window: Sequence[int], n_pr
         dist = (i.view(1, -1) - i.view(-1, 1) + w[a] - 1).clamp(0, 2 * w[a] - 2)  # [i(query), j(key)]
         per_axis.append(table[:, dist])                       # [heads, w, w]
     Rh, Rw, Rd = per_axis
+    if emulate_bf16:
+        s3 = scale / 3.0
+        fold = Rd[:, w[2] - 1, :]                             # [heads, k2]: the dropped column (query i2 = w2-1)
+        q16 = lambda t: r16(t * (s3 * LOG2E)) / (s3 * LOG2E)
+        # Rh + fold depends on (i0, k0, k2); Rd - fold on (i2, k2) and is exactly zero in the dropped column
+        Rhf = q16(Rh[:, :, None, None, :, None, None] + fold[:, None, None, None, None, None, :])
+        Rdf = q16(Rd - fold[:, None, :])
+        content = (Rhf + q16(Rw)[:, None, :, None, None, :, None] + Rdf[:, None, None, :, None, None, :]) / 3
+        heads = content.shape[0]
+        N = w[0] * w[1] * w[2]
+        content = content.reshape(heads, N, N) * scale
+        if n_prompt == 0:
+            return content
+        tok = r16((sd[f"{prefix}pe.weights_token"] @ sd[f"{prefix}pe.enc_token.0"].t()) * (scale * LOG2E)) / LOG2E
+        return torch.cat([content, tok[:, None, :n_prompt].expand(heads, N, n_prompt)], dim=2)
     content = (Rh[:, :, None, None, :, None, None]
                + Rw[:, None, :, None, None, :, None]
                + Rd[:, None, None, :, None, None, :]) / 3
@@ -170,7 +208,8 @@ def shift_mask(geo: BlockGeometry) -> Optional[Tensor]:
 # ----------------------------------------------------------------------------
 def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
                      bias: Optional[Tensor], mask: Optional[Tensor], n_query: int,
-                     attn_keep: Optional[Tensor] = None, proj_keep: Optional[Tensor] = None) -> Tensor:
+                     attn_keep: Optional[Tensor] = None, proj_keep: Optional[Tensor] = None,
+                     emulate_bf16: bool = False) -> Tensor:
     """Windowed MHSA on normalised tokens ``y [B, P, Nk, C]``; returns the
     projected output for the first ``n_query`` rows ``[B, P, n_query, C]``.
 
@@ -194,15 +233,26 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
     q = q.reshape(B, P, n_query, heads, hd).permute(0, 1, 3, 2, 4)
     k = k.reshape(B, P, Nk, heads, hd).permute(0, 1, 3, 2, 4)
     v = v.reshape(B, P, Nk, heads, hd).permute(0, 1, 3, 2, 4)
-    logits = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+    if emulate_bf16:
+        q, k, v = r16(q * (hd ** -0.5)), r16(k * LOG2E) / LOG2E, r16(v)
+        logits = q @ k.transpose(-1, -2)
+    else:
+        logits = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
     if bias is not None:
         logits = logits + bias[None, None]
     if mask is not None:
         logits = logits * mask[None, :, None]
-    prob = logits.softmax(dim=-1)
-    if attn_keep is not None:
-        prob = prob * attn_keep
-    o = (prob @ v).permute(0, 1, 3, 2, 4).reshape(B, P, n_query, C)
+    if emulate_bf16:
+        pe = r16(torch.exp(logits - logits.amax(dim=-1, keepdim=True).detach()))
+        denom = pe.sum(dim=-1, keepdim=True)
+        if attn_keep is not None:
+            pe = pe * attn_keep
+        o = r16((pe @ v) / denom).permute(0, 1, 3, 2, 4).reshape(B, P, n_query, C)
+    else:
+        prob = logits.softmax(dim=-1)
+        if attn_keep is not None:
+            prob = prob * attn_keep
+        o = (prob @ v).permute(0, 1, 3, 2, 4).reshape(B, P, n_query, C)
     out = F.linear(o, sd[f"{prefix}attn.proj.weight"], sd[f"{prefix}attn.proj.bias"])
     if proj_keep is not None:
         out = out * proj_keep
@@ -215,14 +265,18 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
 def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefix: str,
                window: Sequence[int], shift_cfg: Sequence[int], heads: int,
                embed_dim: int = 64, attn_keep: Optional[Tensor] = None,
-               proj_keep: Optional[Tensor] = None) -> Tensor:
+               proj_keep: Optional[Tensor] = None, emulate_bf16: bool = False) -> Tensor:
     """One SwinTransformerBlock, ``x [B,C,H,W,D]`` -> same shape (dropout only through the explicit
     multiplier masks of ``window_attention``).
 
     Follows swin_block.py:145-255.  ``prompt``
     is ``[Np, C]`` (the reference broadcasts the same tokens to every batch
     element and window, swin_unetr.py:55-60, swin_block.py:206-212).
+
+    ``emulate_bf16`` rounds at the HIP path's storage points: both LayerNorm outputs, q/k/v, P, o (see
+    ``window_attention``), the post-attention residual t1 and the block output.
     """
+    rr = r16 if emulate_bf16 else (lambda t: t)
     B, C = x.shape[:2]
     geo = BlockGeometry(x.shape[2:], window, shift_cfg)
     xl = x.permute(0, 2, 3, 4, 1)
@@ -237,14 +291,14 @@ def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefi
         tok_all = torch.cat([tok, prompt[None, None].expand(B, geo.P, n_prompt, C)], dim=2)
     else:
         tok_all = tok
-    y = F.layer_norm(tok_all, (C,), sd[f"{prefix}attn_norm.weight"], sd[f"{prefix}attn_norm.bias"], 1e-6)
-    bias = rel_pos_bias(sd, prefix, window, n_prompt, embed_dim)
+    y = rr(F.layer_norm(tok_all, (C,), sd[f"{prefix}attn_norm.weight"], sd[f"{prefix}attn_norm.bias"], 1e-6))
+    bias = rel_pos_bias(sd, prefix, window, n_prompt, embed_dim, emulate_bf16)
     mask = shift_mask(geo)
     if mask is not None and n_prompt:
         mask = torch.cat([mask, mask.new_ones(geo.P, geo.N, n_prompt)], dim=2)   # :189-196
-    t1 = window_attention(y, sd, prefix, heads, bias, mask, geo.N, attn_keep, proj_keep) + tok
-    t2 = t1 + F.linear(F.layer_norm(t1, (C,), sd[f"{prefix}mlp_norm.weight"], sd[f"{prefix}mlp_norm.bias"], 1e-6),
-                       sd[f"{prefix}mlp.weight"], sd[f"{prefix}mlp.bias"])
+    t1 = rr(window_attention(y, sd, prefix, heads, bias, mask, geo.N, attn_keep, proj_keep, emulate_bf16) + tok)
+    t2 = rr(t1 + F.linear(rr(F.layer_norm(t1, (C,), sd[f"{prefix}mlp_norm.weight"], sd[f"{prefix}mlp_norm.bias"], 1e-6)),
+                          sd[f"{prefix}mlp.weight"], sd[f"{prefix}mlp.bias"]))
     out = x.new_zeros(B, geo.padded[0] * geo.padded[1] * geo.padded[2], C)
     out[:, idx.reshape(-1)] = t2.reshape(B, -1, C)
     out = out.reshape((B,) + geo.padded + (C,))
@@ -255,21 +309,25 @@ def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefi
 
 
 def swin_pair(x: Tensor, prompts, sd: Dict[str, Tensor], prefix: str, window: Sequence[int],
-              heads: int, embed_dim: int = 64, down: bool = True, merge_last_dim: bool = True) -> Tensor:
+              heads: int, embed_dim: int = 64, down: bool = True, merge_last_dim: bool = True,
+              emulate_bf16: bool = False) -> Tensor:
     """ConsecutiveSwinBlocks: W-MSA block, SW-MSA block (shift = w // 2), optional
     PatchMerging.  Follows swin_block.py:36-71."""
     shift = tuple(int(w) // 2 for w in window)
-    x = swin_block(x, prompts[0], sd, f"{prefix}swin_blocks.0.", window, (0, 0, 0), heads, embed_dim)
-    x = swin_block(x, prompts[1], sd, f"{prefix}swin_blocks.1.", window, shift, heads, embed_dim)
+    x = swin_block(x, prompts[0], sd, f"{prefix}swin_blocks.0.", window, (0, 0, 0), heads, embed_dim,
+                   emulate_bf16=emulate_bf16)
+    x = swin_block(x, prompts[1], sd, f"{prefix}swin_blocks.1.", window, shift, heads, embed_dim,
+                   emulate_bf16=emulate_bf16)
     if down:
-        x = patch_merge(x, sd, f"{prefix}merge.", merge_last_dim)
+        x = patch_merge(x, sd, f"{prefix}merge.", merge_last_dim, emulate_bf16)
     return x
 
 
 # ----------------------------------------------------------------------------
 # patch merging  (a11)
 # ----------------------------------------------------------------------------
-def patch_merge(x: Tensor, sd: Dict[str, Tensor], prefix: str, merge_last_dim: bool) -> Tensor:
+def patch_merge(x: Tensor, sd: Dict[str, Tensor], prefix: str, merge_last_dim: bool,
+                emulate_bf16: bool = False) -> Tensor:
     """2x2x2 (or 2x2x1) space-to-depth + LayerNorm(eps 1e-6) + bias-free Linear.
 
     Follows swin_transformer/down.py:21-53.  Odd axes are zero-padded by one AT
@@ -290,7 +348,11 @@ def patch_merge(x: Tensor, sd: Dict[str, Tensor], prefix: str, merge_last_dim: b
     cat = torch.cat(parts, dim=1).permute(0, 2, 3, 4, 1)      # [B, h, w, d, kC]
     kc = cat.shape[-1]
     y = F.layer_norm(cat, (kc,), sd[f"{prefix}norm.weight"], sd[f"{prefix}norm.bias"], 1e-6)
+    if emulate_bf16:                                          # LayerNorm output and the merged tokens are stored as bf16
+        y = r16(y)
     y = F.linear(y, sd[f"{prefix}reduction.weight"])
+    if emulate_bf16:
+        y = r16(y)
     return y.permute(0, 4, 1, 2, 3).contiguous()
 
 
@@ -313,7 +375,8 @@ def batch_norm_train(x: Tensor, sd: Dict[str, Tensor], prefix: str, eps: float, 
 
 def up_block(x: Tensor, skip: Tensor, prompts, sd: Dict[str, Tensor], prefix: str,
              strides: Sequence[int], window: Sequence[int], heads: int, embed_dim: int = 64,
-             training: bool = True, new_buffers: Optional[Dict[str, Tensor]] = None) -> Tensor:
+             training: bool = True, new_buffers: Optional[Dict[str, Tensor]] = None,
+             emulate_bf16: bool = False) -> Tensor:
     """SwinUpBlock: trilinear upsample (align_corners=False) -> crop to skip ->
     concat [up, skip] -> BatchNorm3d(eps 1e-5) -> LeakyReLU(0.01) -> Conv3d 3^3 p1
     (+bias) -> two Swin blocks without merge.
@@ -325,8 +388,10 @@ def up_block(x: Tensor, skip: Tensor, prompts, sd: Dict[str, Tensor], prefix: st
     """
     up = F.interpolate(x, scale_factor=tuple(float(s) for s in strides), mode="trilinear", align_corners=False)
     up = up[..., :skip.shape[2], :skip.shape[3], :skip.shape[4]]
-    cat = torch.cat([up, skip], dim=1)
+    rr = r16 if emulate_bf16 else (lambda t: t)              # stored: the concatenated tensor, act(BN(.)), the conv output
+    cat = rr(torch.cat([up, skip], dim=1))
     y = batch_norm_train(cat, sd, f"{prefix}norm_concat.", 1e-5, training, new_buffers)
-    y = F.leaky_relu(y, 0.01)
-    y = F.conv3d(y, sd[f"{prefix}conv_concat.conv.weight"], sd[f"{prefix}conv_concat.conv.bias"], padding=1)
-    return swin_pair(y, prompts, sd, f"{prefix}swin_layer.", window, heads, embed_dim, down=False)
+    y = rr(F.leaky_relu(y, 0.01))
+    y = rr(F.conv3d(y, sd[f"{prefix}conv_concat.conv.weight"], sd[f"{prefix}conv_concat.conv.bias"], padding=1))
+    return swin_pair(y, prompts, sd, f"{prefix}swin_layer.", window, heads, embed_dim, down=False,
+                     emulate_bf16=emulate_bf16)

@@ -207,7 +207,11 @@ class OracleSwinUnetR:
     segmentation.py:95 + swin_unetr.py:33-40).
     """
 
-    def __init__(self, conf: Namespace, sd: Optional[Dict[str, Tensor]] = None, seed: int = 0):
+    def __init__(self, conf: Namespace, sd: Optional[Dict[str, Tensor]] = None, seed: int = 0,
+                 emulate_bf16: bool = False):
+        """``emulate_bf16``: round to bf16 wherever the HIP path stores a bf16 activation (swin_ref.r16; default path
+        only: ``unetr_res_block in ('none', 'simple')``).  The arithmetic stays the reference's fp32 arithmetic."""
+        self.emulate_bf16 = emulate_bf16
         if conf.training_mode not in TRAINING_MODES:
             raise ValueError(f"Training mode {conf.training_mode} not available!")
         if conf.unetr_up_block != "swin":
@@ -223,6 +227,8 @@ class OracleSwinUnetR:
         ps = tuple(conf.input_patch_size)
         enc = F.conv3d(x, sd["input_layer.0.weight"], sd["input_layer.0.bias"], stride=ps)
         enc = S.batch_norm_train(enc, sd, "input_layer.1.", 1e-6, training, nb)
+        if self.emulate_bf16:
+            enc = S.r16(enc)
         feats.insert(0, enc)
         for j in range(conf.depth_unet):
             if conf.use_encoder_prompting:
@@ -231,7 +237,7 @@ class OracleSwinUnetR:
                 pr = (None, None)
             enc = S.swin_pair(enc, pr, sd, f"encoder_blocks.{j}.", conf.attn_window_size,
                               conf.num_heads_encoder * (2 ** j), conf.pos_bias_embed_dim,
-                              down=True, merge_last_dim=(j < 1))
+                              down=True, merge_last_dim=(j < 1), emulate_bf16=self.emulate_bf16)
             feats.insert(0, enc)
         return feats
 
@@ -244,6 +250,8 @@ class OracleSwinUnetR:
             dec = basic_block_forward(c0, sd, "bottleneck.", conf.basic_block_res) + c0
         else:
             dec = F.conv3d(c0, sd["bottleneck.weight"], sd["bottleneck.bias"], padding=1) + c0
+            if self.emulate_bf16:
+                dec = S.r16(dec)
         for j in range(depth):
             if conf.use_decoder_prompting:
                 pr = (sd[f"prompt_tokens.dec.{2 * j}"], sd[f"prompt_tokens.dec.{2 * j + 1}"])
@@ -252,11 +260,13 @@ class OracleSwinUnetR:
             skip = feats[j + 1]
             if conf.unetr_res_block == "simple":
                 skip = F.conv3d(skip, sd[f"residual_blocks.{j}.weight"], sd[f"residual_blocks.{j}.bias"], padding=1)
+                if self.emulate_bf16:
+                    skip = S.r16(skip)
             elif conf.unetr_res_block == "full":
                 skip = basic_block_forward(skip, sd, f"residual_blocks.{j}.", conf.basic_block_res)
             strides = (2, 2, 1 if j < depth - 1 else 2)
             dec = S.up_block(dec, skip, pr, sd, f"decoder_blocks.{j}.", strides, conf.attn_window_size,
-                             conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb)
+                             conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb, self.emulate_bf16)
         if conf.unetr_res_block == "none":
             return F.interpolate(dec, scale_factor=(2.0, 2.0, 2.0), mode="trilinear", align_corners=False)
         if conf.use_decoder_prompting:
@@ -268,7 +278,7 @@ class OracleSwinUnetR:
         else:
             skip = F.conv3d(feats[-1], sd[f"residual_blocks.{depth}.weight"], sd[f"residual_blocks.{depth}.bias"], padding=1)
         return S.up_block(dec, skip, pr, sd, "output_layer.", (2, 2, 2), conf.attn_window_size,
-                          conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb)
+                          conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb, self.emulate_bf16)
 
     def _head(self, name: str, latent: Tensor, training: bool, nb) -> Tensor:
         sd = self.sd

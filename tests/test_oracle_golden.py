@@ -174,3 +174,26 @@ def test_full_model(tag):
             assert torch.allclose(nb[k], v, rtol=1e-4, atol=1e-6), k
         else:
             assert int(nb[k]) == int(v), k
+
+
+@pytest.mark.parametrize("tag", ["nopad_shift_prompt", "oddpad_shift_prompt", "w442_shift_prompt"])
+def test_rounding_aware_option_stays_near_the_pinned_path(tag):
+    """``emulate_bf16=True`` (the primary bar of the GPU parity tests) is the SAME arithmetic plus bf16 roundings at the
+    HIP path's storage points: on bf16-representable inputs it must stay within a few 2^-9 of the pinned fp32 path, its
+    straight-through gradients likewise, and with the option off nothing changes (the tests above)."""
+    fx = load_fixture(f"block_{tag}")
+    m = fx.meta
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    sd = {k: (r(v) if v.is_floating_point() and v.dim() == 2 and ".pe." not in k and "pe." != k[:3] else v.clone())
+          for k, v in fx["sd"].items()}
+    outs = []
+    for emulate in (False, True):
+        x = r(fx["in"]["x"]).requires_grad_(True)
+        prm = fx["in"]["prompt"].clone().requires_grad_(True)
+        y = S.swin_block(x, prm, sd, "", m["window"], m["shift"], m["heads"], emulate_bf16=emulate)
+        y.backward(r(fx["in"]["gout"]))
+        outs.append((y.detach(), x.grad, prm.grad))
+    (y0, dx0, dp0), (y1, dx1, dp1) = outs
+    assert torch.equal(y1, r(y1))                              # the block output is a stored bf16 tensor
+    assert 1e-4 < rel_l2(y1, y0) < 6e-3
+    assert rel_l2(dx1, dx0) < 1.5e-2 and rel_l2(dp1, dp0) < 1.5e-2
