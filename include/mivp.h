@@ -148,6 +148,18 @@ int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, co
                          const int32_t* tok_rid, const void* o, const void* d_o, const float* lse, float* delta,
                          void* dq, mivp_stream_t stream);
 
+/* ONE-PASS attention backward for head_dim <= 16 (every encoder stage, the last decoder stage): dq, dk, dv and the prompt
+ * partials of the two passes above from a single launch that forms S, dP and the exponentials once per (query, key) pair
+ * (csrc/swin_bwd_fused.hip; autograd of window_attention.py:49-61 with the prompt keys of swin_block.py:187-225).
+ * Same operand layouts as mivp_win_attn_bwd_dq / _dkv; delta is computed internally.  mivp_win_attn_bwd_fused_supported
+ * returns 1 when the shape is covered (otherwise use the two-pass entries). */
+int mivp_win_attn_bwd_fused_supported(const MivpSwinDesc* d);
+int mivp_win_attn_bwd_fused(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
+                            const void* kp, const void* vp, const void* qa, const void* ka,
+                            const int32_t* tok_rid, const void* o, const void* d_o, const float* lse,
+                            void* dq, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
+                            mivp_stream_t stream);
+
 /* key-owner pass: dk, dv [B*P][heads][Nqp][hd] bf16 for window keys;
  *   dkp_part, dvp_part [B*P][heads][Npp][hd] f32 and dtok_part [B*P][heads][Npp] f32:
  *   per-window partial sums for the prompt keys (reduced by mivp_reduce_rows)            */

@@ -1,0 +1,396 @@
+// Window-attention backward in ONE pass (head_dim <= 16: every encoder stage and the last decoder stage).
+// Reference semantics: multi_head_attention/window_attention.py:49-61 (autograd of it), swin_block.py:187-225
+// (prompt keys, multiplicative shift mask).  Replaces the dq-owner + dkv-owner pair of swin_bwd.hip for these shapes:
+// S, dP and the exponentials are formed ONCE per (query tile, key tile).
+//
+// One workgroup (8 waves) owns one (window, head): ALL its queries and ALL its keys.
+//   * wave w owns key tiles w, w+8, w+16, (w+24): K' / V fragments live in registers for the whole kernel, dK^T / dV^T
+//     accumulate in registers (no cross-wave sum);
+//   * the workgroup walks the query tiles t = 0, 1, ... together.  Per tile every wave forms, for each of its key tiles,
+//         S  = Q' K'^T - lse        (16x16x32 MFMA, key on the lane, accumulator starts at -lse * log2 e)
+//         dP = dO V^T - delta       (16x16x16 MFMA, accumulator starts at -delta)
+//         P  = exp2(S), dS = P * dP
+//     feeds P / dS -- already in B-operand position -- to dV^T += dO^T P and dK^T += Q^T dS (16x16x16 MFMAs whose A
+//     operands are TRANSPOSING reads, ds_read_b64_tr_b16, of the same Q' / dO row images the S / dP products read by rows:
+//     no transposed copies are staged);
+//   * dQ^T = K^T dS^T needs dS with the QUERY on the lane: the wave parks its dS tiles (bf16) in a private LDS slot, reads
+//     them back transposed and forms the partial dQ^T of the query tile over ITS keys (one 16x16x16 MFMA per key tile);
+//     the eight partials meet in LDS ([wave][query][head dim] f32, double buffered) and after the tile's barrier ONE wave
+//     (rotating) adds them in wave order and stores dq -- one barrier per query tile, nothing serial in between.
+//     (First form of this kernel: one wave formed dQ of a whole query tile from a shared dS image, a 13-step dependent
+//     LDS-read -> MFMA chain that every other wave waited for at the next barrier: 2.3x slower.)
+// Prompt keys (key tiles beyond Nqp) produce per-window f32 partials of dKp / dVp and the column sums of dS (the gradient
+// of the prompt-token bias), as the two-pass kernels did.  delta = sum_j dO * O is computed while staging dO.
+//
+// LDS (7^3 window + 64 prompt keys: 77 KB -> two workgroups per CU):
+//   Qimg  [nq][64 B]   Q' rows (head dims | bias one-hots), 16-byte chunks XOR-swizzled (common.hpp OperandRows<32>)
+//   Oimg  [nq][32 B]   dO rows (16 columns), the two 16-byte halves swapped in rows 8..15 of every 16
+//   Kt    [16][Nkp+8]  K^T (head dims x keys) for the dQ product
+//   exch  [Nkp/16][512 B]  dS of the current query tile, one slot per key tile (private to the owning wave): element
+//         (key r, query quad p) at 128 p + 8 (r ^ 8 (p >> 1)) -- conflict-free for the 8-byte writes and the transposed reads
+//   dqp   [2][8 waves][16 queries][16] f32  partial dQ^T tiles
+//   lse_s, del_s [nq] f32, ridq [nq] bytes
+// Every reduction has a fixed order: results are bit-reproducible.
+#include "common.hpp"
+
+int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+MIVP_DEV f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+// f32x4 -> four bf16 as exactly two v_cvt_pk_bf16_f32.  The value feeds BOTH an LDS store and the short-typed operand of
+// the K = 16 MFMA builtin; converted element by element that second use became four single conversions plus two v_perm
+// per pack (10 + 4 VALU instructions per tile instead of 4, in a VALU-issue-bound loop).  Converting PAIRS and carrying
+// the result as two dwords keeps it at two instructions.  (Not inline asm: hipcc pads no VALU -> MFMA-operand wait states
+// around an asm statement, and a first asm form of this returned garbage on the large shapes.)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+MIVP_DEV u32x2 pack4_pk(f32x4 v) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    u32x2 u;
+    u[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+    u[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
+    return u;
+}
+MIVP_DEV f32x4 mfma16k16(bf16x4 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+// 4 rows x 16 columns of bf16 per 16-lane group, delivered column-major: lane 4q+p of the group passes the address of row
+// q, columns 4p..4p+3; lane i receives column i of the four rows (EXEC must be full: callers keep the wave converged)
+MIVP_DEV bf16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+}
+
+constexpr int FUSED_KPW = 4;                                   // key tiles per wave (8 waves: up to 512 keys)
+using KR = OperandRows<32>;
+
+MIVP_DEV int oimg_off(int row, int byte) { return row * 32 + (byte ^ (((row >> 3) & 1) << 4)); }
+MIVP_DEV int exch_off(int tile, int key, int quad) { return tile * 512 + 128 * quad + 8 * (key ^ ((quad >> 1) << 3)); }
+
+}  // namespace
+
+template <int NW, bool DROP, bool MASKED>
+__global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
+    MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
+    const bf16_t* __restrict__ ka, const int* __restrict__ tok_rid, const bf16_t* __restrict__ o,
+    const bf16_t* __restrict__ d_o, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+    bf16_t* __restrict__ dv, float* __restrict__ dkp_part, float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a SCALAR: everything derived from it (key-tile ownership, LDS slots) stays in SGPRs and the
+    // per-tile "does this wave own a fourth key tile" tests are scalar branches, not exec-masked regions
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
+    const int hd4 = hd / 4, a4 = A / 4;
+    const long bph = blockIdx.x;
+    const int head = (int)(bph % heads);
+    const long bp = bph / heads;
+    const int pw = (int)(bp % d.P);
+    const int nt = Nkp / 16;                                  // key tiles
+    const int nqt = (Nqp + 31) / 32 * 2;                      // query tiles, rounded to an even count (phantom tile: P = 0)
+    const int nq = nqt * 16;
+    const int KTROW = (Nkp + 8) * 2;
+
+    char* Qimg = smem;
+    char* Oimg = Qimg + (size_t)nq * 64;
+    char* Kt = Oimg + (size_t)nq * 32;
+    char* exch = Kt + (size_t)hd * KTROW;
+    float* dqp = reinterpret_cast<float*>(exch + (size_t)nt * 512);
+    float* lse_s = dqp + 2 * NW * 256;
+    float* del_s = lse_s + nq;
+    uint8_t* ridq = reinterpret_cast<uint8_t*>(del_s + nq);
+
+    const bf16_t* qb = q + bph * (long)Nqp * hd;             // uniform per-(window, head) bases, 32-bit offsets
+    const bf16_t* kb = k + bph * (long)Nqp * hd;
+    const bf16_t* vb = v + bph * (long)Nqp * hd;
+    const bf16_t* kpb = d.Np > 0 ? kp + (long)head * d.Npp * hd : kb;
+    const bf16_t* vpb = d.Np > 0 ? vp + (long)head * d.Npp * hd : vb;
+    const bf16_t* kab = ka + (long)head * Nkp * A;
+    const bf16_t* dob = d_o + bp * (long)Nqp * C + head * hd;
+    const bf16_t* ob = o + bp * (long)Nqp * C + head * hd;
+    const float* lseb = lse + bph * (long)Nqp;
+    const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+
+    // ---------------- staging ----------------
+    // Q' rows: [head dims | bias one-hots | zero], 8-byte pieces
+    for (int e = tid; e < nq * 8; e += 64 * NW) {
+        const int lrow = e >> 3, c4 = e & 7;
+        bf16x4 val = zero4();
+        if (lrow < Nqp) {
+            if (c4 < hd4) val = ld4(qb + ((uint32_t)lrow * hd + 4 * c4));
+            else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)lrow * A + 4 * (c4 - hd4)));
+        }
+        *reinterpret_cast<bf16x4*>(Qimg + KR::off(lrow, 4 * c4)) = val;
+    }
+    // dO rows + delta = sum_j dO * O: four consecutive lanes share a query row (the loop bound is a multiple of the wave
+    // size, so the shuffles see converged waves)
+    for (int e = tid; e < nq * 4; e += 64 * NW) {
+        const int lrow = e >> 2, c4 = e & 3;
+        bf16x4 gv = zero4(), ov = zero4();
+        if (lrow < Nqp && c4 < hd4) {
+            gv = ld4(dob + ((uint32_t)lrow * C + 4 * c4));
+            ov = ld4(ob + ((uint32_t)lrow * C + 4 * c4));
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += (float)gv[i] * (float)ov[i];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        *reinterpret_cast<bf16x4*>(Oimg + oimg_off(lrow, 8 * c4)) = gv;
+        if (c4 == 0) del_s[lrow] = -part;
+    }
+    for (int m = tid; m < nq; m += 64 * NW) {
+        const bool ok = m < Nqp;
+        lse_s[m] = ok ? -lseb[m] * MIVP_LOG2E : -INFINITY;    // the S accumulators start from it; padding query rows: P = 0
+        ridq[m] = (uint8_t)((ok && m < d.Nq) ? (MASKED ? tok_rid[pw * Nqp + m] : 0) : 255);
+    }
+    // K^T (head dims x keys): four consecutive keys of one 4-channel group, transposed 4x4 in registers.  The image has hd
+    // rows: lanes that would read rows hd..15 of the A operand re-read row 0 (row j of A only reaches row j of dQ^T, and
+    // rows >= hd are never stored).
+    for (int e = tid; e < (Nkp / 4) * hd4; e += 64 * NW) {
+        const int c4 = e % hd4, k4 = e / hd4;
+        bf16x4 in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * k4 + i;
+            bf16x4 val = zero4();
+            if (row < Nqp) val = ld4(kb + ((uint32_t)row * hd + 4 * c4));
+            else if (row < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(row - Nqp) * hd + 4 * c4));
+            in[i] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 outv;
+            outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
+            *reinterpret_cast<bf16x4*>(Kt + (size_t)(4 * c4 + j) * KTROW + 2 * (4 * k4)) = outv;
+        }
+    }
+    // this wave's key tiles: K' / V fragments (B operands) from global, once
+    bf16x8 kf[FUSED_KPW];
+    bf16x4 vf[FUSED_KPW];
+    uint32_t kk[FUSED_KPW];                                    // mask operand: live = ((rq | pm) == kk), pm = kk's sign spread
+    f32x4 dkacc[FUSED_KPW], dvacc[FUSED_KPW];
+    f32x2 dsum[FUSED_KPW];                                     // column sums of dS, two partial sums per lane
+#pragma unroll
+    for (int i = 0; i < FUSED_KPW; ++i) {
+        const int kt = wave + NW * i;
+        const int krow = (kt < nt ? kt : 0) * 16 + r;
+        bf16x4 piece[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 2 * g + hlf;
+            bf16x4 val = zero4();
+            if (c4 < hd4) {
+                if (krow < Nqp) val = ld4(kb + ((uint32_t)krow * hd + 4 * c4));
+                else if (krow < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
+            } else if (c4 < hd4 + a4) {
+                val = ld4(kab + ((uint32_t)krow * A + 4 * (c4 - hd4)));
+            }
+            piece[hlf] = val;
+        }
+        kf[i] = cat44(piece[0], piece[1]);
+        bf16x4 vv = zero4();
+        if (g < hd4) {
+            if (krow < Nqp) vv = ld4(vb + ((uint32_t)krow * hd + 4 * g));
+            else if (krow < Nqp + n_prompt_rows) vv = ld4(vpb + ((uint32_t)(krow - Nqp) * hd + 4 * g));
+        }
+        vf[i] = vv;
+        // content key: its region id; prompt and padding keys are never masked (padding keys are excluded by their bias)
+        const bool content = krow < d.Nq;
+        const uint32_t cls = (MASKED && content) ? (uint32_t)tok_rid[pw * Nqp + krow] : 0u;
+        kk[i] = content ? cls : 0xFFFFFFFFu;
+        dkacc[i] = fzero4();
+        dvacc[i] = fzero4();
+        dsum[i] = f32x2{0.f, 0.f};
+    }
+    // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op
+    bool cut = false;
+    if (MASKED) {
+        const int first = tok_rid[pw * Nqp];
+        int differs = 0;
+        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= tok_rid[pw * Nqp + m] != first;
+        cut = __syncthreads_or(differs) != 0;
+    }
+    __syncthreads();
+
+    const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
+    const char* ktrow = Kt + (size_t)(r < hd ? r : 0) * KTROW;  // this lane's row of the dQ product's A operand
+
+    // dQ of query tile t: the eight waves' partial tiles (buffer t & 1) added in wave order
+    auto dq_store = [&](int t) {
+        const float* src = dqp + (size_t)(t & 1) * NW * 256 + r * 16 + 4 * g;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) acc = acc + *reinterpret_cast<const f32x4*>(src + w * 256);
+        const int qrow = 16 * t + r;
+        if (qrow < Nqp && 4 * g < hd)
+            st4(dq + ((bph * Nqp + qrow) * (long)hd + 4 * g), pack4(acc * MIVP_LN2));      // K carries log2(e)
+    };
+
+    // lane-constant parts of every LDS address of the tile loop (the t-dependent part is a multiple of the tile stride:
+    // the row swizzles of Qimg / Oimg repeat every 16 rows)
+    const char* q_rd = Qimg + KR::off(r, 8 * g);                                   // + 1024 t : S operand row of this lane
+    const char* q_tr = Qimg + KR::off(4 * g + (r >> 2), 4 * (r & 3));              // + 1024 t : Q'^T block for dK^T
+    const char* o_rd = Oimg + oimg_off(r, 8 * g);                                  // +  512 t : dP operand row
+    const char* o_tr = Oimg + oimg_off(4 * g + (r >> 2), 8 * (r & 3));             // +  512 t : dO^T block for dV^T
+    char* ex_wr = exch + exch_off(wave, r, g);                                     // + 4096 i : this wave's slot, as written
+    const char* ex_tr = exch + exch_off(wave, 4 * g + (r >> 2), r & 3);            // + 4096 i : ... as read back transposed
+    const char* kt_rd = ktrow + (16 * wave + 4 * g) * 2;                           // +  256 i : K^T columns of key tile i
+    float* dqp_wr = dqp + wave * 256 + r * 16 + 4 * g;
+    static_assert(NW == 8, "slot strides below assume eight waves");
+
+    // The tile loop is instantiated per (number of key tiles this wave owns, shift mask in effect): its body is then free
+    // of branches, so the scheduler interleaves the tiles' MFMA -> exp -> multiply -> convert chains (with a scalar
+    // "do I own a fourth tile" test per tile every tile sat in its own basic block behind two s_nop 7).
+    auto walk = [&](auto nt_c, auto cut_c) {
+        constexpr int NT = decltype(nt_c)::value;
+        constexpr bool CUT = decltype(cut_c)::value;
+        for (int t = 0; t < nqt; ++t) {
+            if (t > 0 && wave == ((t - 1) & (NW - 1))) dq_store(t - 1);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
+            const f32x4 n4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_rd + 1024 * t);
+            const bf16x4 of = *reinterpret_cast<const bf16x4*>(o_rd + 512 * t);
+            // A operands of the dK^T / dV^T products: Q'^T and dO^T of this tile by transposing reads (rows 4g..4g+3)
+            const bf16x4 qt = tr_read(q_tr + 1024 * t);
+            const bf16x4 ot = tr_read(o_tr + 512 * t);
+            uint32_t rqs[4] = {0u, 0u, 0u, 0u};
+            if (CUT) {
+                const uint32_t rq4 = *reinterpret_cast<const uint32_t*>(ridq + 16 * t + 4 * g);
+                rqs[0] = rq4 & 0xFFu; rqs[1] = (rq4 >> 8) & 0xFFu; rqs[2] = (rq4 >> 16) & 0xFFu; rqs[3] = rq4 >> 24;
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const f32x4 s = mfma16(qf, kf[i], l4);
+                const f32x4 dp = mfma16k16(of, vf[i], DROP ? fzero4() : n4);
+                f32x4 pv, ds;
+                const uint32_t pm = (uint32_t)((int32_t)kk[i] >> 31);   // all ones for prompt / padding keys (never masked)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float keep = 1.f;
+                    if (DROP) {                                // element (query 16t + 4g + j, key 16 kt + r)
+                        const int krow = 16 * (wave + NW * i) + r;
+                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                        keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
+                    }
+                    const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
+                    float pe, dsv;
+                    if (CUT) {
+                        // a masked logit is the constant 0 (accumulator value l4[j]): it keeps its P, carries no gradient
+                        const bool live = (rqs[j] | pm) == kk[i];
+                        pe = __builtin_amdgcn_exp2f(live ? s[j] : l4[j]);
+                        dsv = live ? pe * dpe : 0.f;
+                    } else {
+                        pe = __builtin_amdgcn_exp2f(s[j]);
+                        dsv = pe * dpe;
+                    }
+                    pv[j] = DROP ? pe * keep : pe;
+                    ds[j] = dsv;
+                }
+                dsum[i] = dsum[i] + (f32x2{ds[0], ds[1]} + f32x2{ds[2], ds[3]});   // only the prompt tiles' sums are used
+                const u32x2 pb = pack4_pk(pv), sb = pack4_pk(ds);
+                *reinterpret_cast<u32x2*>(ex_wr + 4096 * i) = sb;                          // this wave's private slot
+                dkacc[i] = mfma16k16(qt, sb, dkacc[i]);
+                dvacc[i] = mfma16k16(ot, pb, dvacc[i]);
+            }
+            // partial dQ^T [head dim][query] over this wave's keys: B = dS^T by transposing reads of the slots just written
+            // (same wave: ordered by the LDS queue), A = K^T columns of the key tile
+            f32x4 dqa = fzero4();
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const bf16x4 b = tr_read(ex_tr + 4096 * i);
+                const bf16x4 a = *reinterpret_cast<const bf16x4*>(kt_rd + 256 * i);
+                dqa = mfma16k16(a, b, dqa);
+            }
+            *reinterpret_cast<f32x4*>(dqp_wr + (t & 1) * NW * 256) = dqa;
+            __syncthreads();
+        }
+        if (wave == ((nqt - 1) & (NW - 1))) dq_store(nqt - 1);    // (a phantom tile stores nothing)
+    };
+    const int my_nt = wave < nt ? (nt - wave + NW - 1) / NW : 0;   // scalar
+    auto walk_nt = [&](auto cut_c) {
+        switch (my_nt) {
+            case 0: walk(std::integral_constant<int, 0>{}, cut_c); break;
+            case 1: walk(std::integral_constant<int, 1>{}, cut_c); break;
+            case 2: walk(std::integral_constant<int, 2>{}, cut_c); break;
+            case 3: walk(std::integral_constant<int, 3>{}, cut_c); break;
+            default: walk(std::integral_constant<int, 4>{}, cut_c); break;
+        }
+    };
+    if (MASKED && cut) walk_nt(std::true_type{});
+    else walk_nt(std::false_type{});
+
+    // ---------------- results of this wave's key tiles ----------------
+#pragma unroll
+    for (int i = 0; i < FUSED_KPW; ++i) {
+        const int kt = wave + NW * i;
+        if (kt >= nt) continue;
+        const int krow = kt * 16 + r;
+        if (krow < Nqp) {
+            if (4 * g < hd) {
+                st4(dk + ((bph * Nqp + krow) * (long)hd + 4 * g), pack4(dkacc[i]));
+                st4(dv + ((bph * Nqp + krow) * (long)hd + 4 * g), pack4(dvacc[i]));
+            }
+        } else if (krow < Nqp + d.Npp) {
+            const int tp = krow - Nqp;
+            const float dt = col_sum(dsum[i][0] + dsum[i][1]);
+            if (4 * g < hd) {
+                *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + tp) * (long)hd + 4 * g)) = dkacc[i];
+                *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + tp) * (long)hd + 4 * g)) = dvacc[i];
+            }
+            if (g == 0) dtok_part[bph * d.Npp + tp] = dt;
+        }
+    }
+}
+
+static size_t fused_lds_bytes(const MivpSwinDesc* d) {
+    const size_t nq = (size_t)((d->Nqp + 31) / 32 * 2) * 16, nt = d->Nkp / 16;
+    const size_t hd = d->C / d->heads;
+    return nq * 64 + nq * 32 + hd * (size_t)(d->Nkp + 8) * 2 + nt * 512 + 2 * 8 * 256 * sizeof(float) + 2 * nq * sizeof(float) +
+           ((nq + 15) & ~(size_t)15);
+}
+
+/* 1 when mivp_win_attn_bwd_fused covers this shape (head_dim <= 16, head_dim + bias columns <= 32, <= 512 keys, LDS fits) */
+extern "C" int mivp_win_attn_bwd_fused_supported(const MivpSwinDesc* d) {
+    if (!d || d->heads <= 0 || d->C % d->heads) return 0;
+    const int hd = d->C / d->heads;
+    int dks, nt;
+    if (mivp_attn_tile_config(d, &dks, &nt) || dks != 1) return 0;
+    if (hd > 16 || hd % 4 || d->Nkp / 16 > 8 * FUSED_KPW) return 0;
+    return fused_lds_bytes(d) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int mivp_win_attn_bwd_fused(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
+                                       const void* vp, const void* qa, const void* ka, const int32_t* tok_rid,
+                                       const void* o, const void* d_o, const float* lse, void* dq, void* dk, void* dv,
+                                       float* dkp_part, float* dvp_part, float* dtok_part, mivp_stream_t stream) {
+    MIVP_REQUIRE(d != nullptr);
+    MIVP_REQUIRE(d->B > 0 && d->C > 0 && d->heads > 0 && d->P > 0);
+    MIVP_REQUIRE(d->C % 8 == 0 && d->C % d->heads == 0 && (d->C / d->heads) % 4 == 0);
+    MIVP_REQUIRE(d->Nqp % 16 == 0 && d->Npp % 16 == 0 && d->Nkp % 32 == 0 && d->augp % 4 == 0);
+    MIVP_REQUIRE(d->Nkp >= d->Nqp + d->Npp && d->Nqp >= d->Nq);
+    MIVP_REQUIRE((long)d->B * d->P * d->Nqp < (1L << 31));
+    MIVP_REQUIRE(q && k && v && qa && ka && o && d_o && lse && dq && dk && dv);
+    MIVP_REQUIRE(d->Np == 0 || (kp && vp && dkp_part && dvp_part && dtok_part));
+    MIVP_REQUIRE(!d->has_mask || tok_rid);
+    if (!mivp_win_attn_bwd_fused_supported(d)) { mivp_set_error("win_attn_bwd_fused: shape outside the fused kernel's range"); return MIVP_EUNSUPPORTED; }
+    const size_t lds = fused_lds_bytes(d);
+    constexpr int NW = 8;
+    const bool msk = d->has_mask != 0;
+    auto kern = d->attn_drop_thr ? (msk ? k_win_attn_bwd_fused<NW, true, true> : k_win_attn_bwd_fused<NW, true, false>)
+                                 : (msk ? k_win_attn_bwd_fused<NW, false, true> : k_win_attn_bwd_fused<NW, false, false>);
+    MIVP_LDS_OPT_IN(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, (hipStream_t)stream, *d,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp,
+                       (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (const bf16_t*)o, (const bf16_t*)d_o, lse, (bf16_t*)dq,
+                       (bf16_t*)dk, (bf16_t*)dv, dkp_part, dvp_part, dtok_part);
+    return mivp_check_launch("win_attn_bwd_fused");
+}

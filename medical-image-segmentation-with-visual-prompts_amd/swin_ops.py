@@ -14,6 +14,7 @@ from . import _lib as L
 from .geometry import BlockTables, block_tables, round_up
 
 BF16 = torch.bfloat16
+USE_FUSED_ATTN_BWD = True      # one-pass attention backward where it applies (tests flip it to compare with the two-pass form)
 
 
 @dataclass
@@ -240,41 +241,47 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
         wg["wproj"] = ops.gemm_tn(g_pj, rows, sv.o, rows, T, Cc, Cc)
         wg["bproj"] = _colsum_bf16(g_pj.view(T, Cc))
         del n2, dn2, dyw, d_pj
-    delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
     dx = dprompt = dts = None
     dk = dv = None
-    if need_dx:
-        dq = torch.empty_like(sv.q)                      # the dq pass also writes delta for the dkv pass
-        L.call("mivp_win_attn_bwd_dq", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
-               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta),
-               L.ptr(dq), st)
-        dk = torch.empty_like(sv.k)
-        dv = torch.empty_like(sv.v)
-    else:
-        L.call("mivp_win_attn_delta", C.byref(d), L.ptr(sv.o), L.ptr(d_o), L.ptr(delta), st)
     has_prompt = d.Np > 0
     dkp_part = dvp_part = dtok_part = None
-    if has_prompt and need_prompt:
+    if has_prompt and (need_prompt or need_dx):          # the kernels always emit the prompt partials when prompts exist
         dkp_part = torch.empty((BP * heads, d.Npp, hd), dtype=torch.float32, device=dev)
         dvp_part = torch.empty_like(dkp_part)
         dtok_part = torch.empty((BP * heads, d.Npp), dtype=torch.float32, device=dev)
-    if need_dx or (has_prompt and need_prompt):
-        if has_prompt and dkp_part is None:          # kernel always emits the prompt partials when prompts exist
-            dkp_part = torch.empty((BP * heads, d.Npp, hd), dtype=torch.float32, device=dev)
-            dvp_part = torch.empty_like(dkp_part)
-            dtok_part = torch.empty((BP * heads, d.Npp), dtype=torch.float32, device=dev)
-        dka_part = torch.empty((BP * heads, d.Nkp, 32), dtype=torch.float32, device=dev) if need_w else None
-        L.call("mivp_win_attn_bwd_dkv", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
-               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dk), L.ptr(dv),
-               L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), L.ptr(dka_part), st)
-        if need_w:
-            dka = torch.empty((heads, d.Nkp, 32), dtype=torch.float32, device=dev)
-            L.call("mivp_reduce_rows", L.ptr(dka_part), C.c_int64(BP), C.c_int64(heads * d.Nkp * 32), L.ptr(dka), st)
-            del dka_part
-            win = [int(d.win[a]) for a in range(3)]
-            tabs = [torch.empty((heads, 2 * win[a] - 1), dtype=torch.float32, device=dev) for a in range(3)]
-            L.call("mivp_relbias_grad", C.byref(d), L.ptr(dka), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]), st)
-            wg["t_h"], wg["t_w"], wg["t_d"] = tabs
+    fused = need_dx and not need_w and USE_FUSED_ATTN_BWD and bool(L.lib().mivp_win_attn_bwd_fused_supported(C.byref(d)))
+    if fused:
+        # one pass: S, dP and the exponentials once per (query, key) pair (csrc/swin_bwd_fused.hip)
+        dq = torch.empty_like(sv.q)
+        dk = torch.empty_like(sv.k)
+        dv = torch.empty_like(sv.v)
+        L.call("mivp_win_attn_bwd_fused", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
+               L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(dq), L.ptr(dk),
+               L.ptr(dv), L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), st)
+    else:
+        delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
+        if need_dx:
+            dq = torch.empty_like(sv.q)                      # the dq pass also writes delta for the dkv pass
+            L.call("mivp_win_attn_bwd_dq", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
+                   L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta),
+                   L.ptr(dq), st)
+            dk = torch.empty_like(sv.k)
+            dv = torch.empty_like(sv.v)
+        else:
+            L.call("mivp_win_attn_delta", C.byref(d), L.ptr(sv.o), L.ptr(d_o), L.ptr(delta), st)
+        if need_dx or (has_prompt and need_prompt):
+            dka_part = torch.empty((BP * heads, d.Nkp, 32), dtype=torch.float32, device=dev) if need_w else None
+            L.call("mivp_win_attn_bwd_dkv", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
+                   L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(d_o), L.ptr(sv.lse), L.ptr(delta), L.ptr(dk), L.ptr(dv),
+                   L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), L.ptr(dka_part), st)
+            if need_w:
+                dka = torch.empty((heads, d.Nkp, 32), dtype=torch.float32, device=dev)
+                L.call("mivp_reduce_rows", L.ptr(dka_part), C.c_int64(BP), C.c_int64(heads * d.Nkp * 32), L.ptr(dka), st)
+                del dka_part
+                win = [int(d.win[a]) for a in range(3)]
+                tabs = [torch.empty((heads, 2 * win[a] - 1), dtype=torch.float32, device=dev) for a in range(3)]
+                L.call("mivp_relbias_grad", C.byref(d), L.ptr(dka), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]), st)
+                wg["t_h"], wg["t_w"], wg["t_d"] = tabs
     if need_dx:
         dx = torch.empty_like(sv.x)
         dn1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if need_w else None

@@ -318,3 +318,52 @@ def test_patch_merge_backward_real_channels(C, dims, last):
     assert rel_l2(dw.cpu(), sd["reduction.weight"].grad) < 6e-3
     assert rel_l2(dgamma.cpu(), sd["norm.weight"].grad) < 6e-3
     assert rel_l2(dbeta.cpu(), sd["norm.bias"].grad) < 6e-3
+
+
+@pytest.mark.parametrize("window,dims,C,heads,n_prompt,shift,dropout", [
+    ((7, 7, 7), (14, 14, 14), 48, 4, 64, (3, 3, 3), None),            # cut and uncut windows, prompts (26 key tiles)
+    ((7, 7, 7), (14, 14, 14), 48, 4, 0, (0, 0, 0), None),             # decoder stage 2: no prompts (22 key tiles)
+    ((7, 7, 7), (12, 12, 24), 96, 8, 64, (3, 3, 3), None),
+    ((7, 7, 7), (6, 6, 24), 192, 16, 64, (3, 3, 3), (0.1, 0.1, 123, 456)),
+    ((8, 8, 4), (16, 16, 8), 48, 4, 64, (4, 4, 2), None),             # 256-token windows: 20 key tiles
+    ((5, 5, 3), (10, 10, 6), 48, 4, 16, (2, 2, 1), None),             # 75 queries -> 5 query tiles: the phantom sixth tile
+    ((3, 3, 2), (6, 6, 4), 16, 4, 8, (1, 1, 1), (0.2, 0.0, 9, 10)),   # head_dim 4, tiny windows
+])
+def test_one_pass_backward_equals_two_pass(window, dims, C, heads, n_prompt, shift, dropout):
+    """csrc/swin_bwd_fused.hip against the dq-owner + dkv-owner pair it replaces (swin_bwd.hip), same inputs: both form the
+    same products with fp32 accumulation and round dS / P to bf16 at the same points, so dq / dk / dv (through dx) and the
+    prompt gradients agree to summation-order noise -- a wrong tile, lane map or mask would be an O(1) difference."""
+    import mivp_amd
+    from mivp_amd import swin_ops
+    from oracle.unetr_ref import _block_state
+    gen = torch.Generator().manual_seed(3)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, max(n_prompt, 1), n_prompt > 0, gen)
+    sd = _rounded_state(sd)
+    x = r16(torch.randn(2, C, *dims, generator=gen))
+    prm = 0.5 * torch.randn(n_prompt, C, generator=gen) if n_prompt else None
+    gout = r16(torch.randn(2, C, *dims, generator=gen))
+    w = swin_ops.weights_from_state(sd, "", heads, 64, n_prompt, torch.device(DEV), need_bwd=True)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = None if prm is None else prm.to(DEV)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        swin_ops.USE_FUSED_ATTN_BWD = fused
+        try:
+            y, saved = swin_ops.swin_block_forward(xc, pd, w, None, window, shift, save=True, dropout=dropout)
+            if fused:
+                import ctypes
+                from mivp_amd import _lib as L
+                assert L.lib().mivp_win_attn_bwd_fused_supported(ctypes.byref(saved.desc)) == 1
+            res.append(swin_ops.swin_block_backward(saved, w, pd, dy, True, n_prompt > 0))
+        finally:
+            swin_ops.USE_FUSED_ATTN_BWD = True
+    torch.cuda.synchronize()
+    (dx1, dp1, dt1), (dx2, dp2, dt2) = res
+    assert torch.isfinite(dx1.float()).all()
+    e = rel_l2(dx1.float().cpu(), dx2.float().cpu())
+    assert e < 2.5e-3, ("dx", e)                                # two bf16 roundings of nearly equal f32 values
+    if n_prompt:
+        assert rel_l2(dp1.cpu(), dp2.cpu()) < 1e-3 and rel_l2(dt1.cpu(), dt2.cpu()) < 1e-3, \
+            (rel_l2(dp1.cpu(), dp2.cpu()), rel_l2(dt1.cpu(), dt2.cpu()))
