@@ -473,6 +473,28 @@ int mivp_add_bf16(const void* a, const void* b, int64_t n, void* y, mivp_stream_
 /* MFMA lane-map self test: c[16][16] f32 = a[16][32] * b[16][32]^T via one 16x16x32 MFMA */
 int mivp_selftest_mfma(const void* a, const void* b, float* c, mivp_stream_t stream);
 
+/* ---- students/teacher objective and optimizer side ---------------------------------------------------
+ * Point sampling of clustered_prototype_loss.py:162-204 (identity affine_grid + bilinear grid_sample, align_corners = False,
+ * on an optional jitter crop): out f32 [B][o0*o1*o2][C] from vol [B][H][W][D][C] (channels_last) or [B][C][H][W][D], bf16 or
+ * f32.  lo / hi / w: per axis, per output index: absolute voxel coordinates of the two taps and the weight of the upper one
+ * (arrays of three device pointers).  The backward is a gather over voxels: per axis and voxel coordinate up to two
+ * (output index, weight) pairs (index -1 = none); gvol bf16 [B][H][W][D][C], C % 8 == 0. */
+int mivp_sample_points_fwd(const void* vol, int32_t is_bf16, int32_t channels_last, int32_t B, int32_t H, int32_t W, int32_t D,
+                           int32_t C, const int32_t* out_dims, const int32_t* const* lo, const int32_t* const* hi,
+                           const float* const* w, float* out, mivp_stream_t stream);
+int mivp_sample_points_bwd(const float* gout, int32_t B, int32_t H, int32_t W, int32_t D, int32_t C, const int32_t* out_dims,
+                           const int32_t* const* i1, const int32_t* const* i2, const float* const* w1, const float* const* w2,
+                           void* gvol, mivp_stream_t stream);
+/* torch.optim.AdamW over many tensors in one launch (students_teacher.py:27-68, segmentation.py:25-39).
+ * tensors: device array of {float* p, float* exp_avg, float* exp_avg_sq, int64 n, int32 group, int32 pad} (40 bytes);
+ * grads: device array of float* (same order); groups: HOST array [n_groups][8] f32 = {lr, beta1, beta2, eps, weight_decay,
+ * 1 - beta1^step, sqrt(1 - beta2^step), 0}; chunks: device int32 [n_chunks][2] = (tensor index, 1024-element chunk). */
+int mivp_adamw_multi(const void* tensors, const void* grads, const float* groups, int32_t n_groups, const void* chunks,
+                     int32_t n_chunks, mivp_stream_t stream);
+/* EMA teacher update (momentum_model.py:27-36): tensors = device array of {float* teacher, const float* student, int64 n} */
+int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream);
+int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2: EMA record */
+
 #ifdef __cplusplus
 }
 #endif

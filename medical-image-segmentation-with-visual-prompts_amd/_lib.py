@@ -111,48 +111,53 @@ def call(name, *args):
 # ---------------------------------------------------------------------------------------------
 # optional per-kernel timing (bench.py): HIP events on the stream the kernel is launched on
 # ---------------------------------------------------------------------------------------------
-_prof = {"name": (), "pred": None, "on": False, "events": [], "desc": None, "entry": None}
+_prof = {"on": False, "sel": {}}          # key -> {"names": (...), "pred": callable | None, "events": [], "desc": ..., "entry": ...}
 
 
-def profile_select(name, pred=None):
+def profile_select(name, pred=None, key="roofline"):
     """Time every call of C-ABI entry ``name`` (a name or a tuple of names) whose ctypes args satisfy ``pred`` while
-    profiling is on."""
-    _prof.update(name=(name,) if isinstance(name, str) else tuple(name), pred=pred, events=[], desc=None, entry=None)
+    profiling is on; several selections can be active under different ``key``s."""
+    _prof["sel"][key] = {"names": (name,) if isinstance(name, str) else tuple(name), "pred": pred, "events": [],
+                         "desc": None, "entry": None}
 
 
 def profile_reset(on: bool):
     if on:
-        _prof["events"] = []
+        for s in _prof["sel"].values():
+            s["events"] = []
     _prof["on"] = on
 
 
-def profile_result():
-    """(mean launch duration in ms, launches, descriptor of the last timed launch); ``profile_entry()`` names it."""
-    ev = _prof["events"]
-    if not ev:
+def profile_result(key="roofline"):
+    """(mean launch duration in ms, launches, descriptor of the last timed launch); ``profile_entry(key)`` names it."""
+    s = _prof["sel"].get(key)
+    if not s or not s["events"]:
         return 0.0, 0, None
     torch.cuda.synchronize()
-    ms = [a.elapsed_time(b) for a, b in ev]
-    return sum(ms) / len(ms), len(ms), _prof["desc"]
+    ms = [a.elapsed_time(b) for a, b in s["events"]]
+    return sum(ms) / len(ms), len(ms), s["desc"]
 
 
-def profile_entry():
-    return _prof["entry"]
+def profile_entry(key="roofline"):
+    s = _prof["sel"].get(key)
+    return s["entry"] if s else None
 
 
 _plain_call = call
 
 
 def call(name, *args):  # noqa: F811  (wraps the plain call with the optional event pair)
-    if _prof["on"] and name in _prof["name"] and (_prof["pred"] is None or _prof["pred"](args)):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        _plain_call(name, *args)
-        b.record()
-        _prof["events"].append((a, b))
-        d = args[0]._obj
-        _prof["desc"] = type(d).from_buffer_copy(d)
-        _prof["entry"] = name
-        return
+    if _prof["on"]:
+        for s in _prof["sel"].values():
+            if name in s["names"] and (s["pred"] is None or s["pred"](args)):
+                a = torch.cuda.Event(enable_timing=True)
+                b = torch.cuda.Event(enable_timing=True)
+                a.record()
+                _plain_call(name, *args)
+                b.record()
+                s["events"].append((a, b))
+                d = args[0]._obj
+                s["desc"] = type(d).from_buffer_copy(d)
+                s["entry"] = name
+                return
     _plain_call(name, *args)

@@ -1,0 +1,150 @@
+"""Optimizer side of the reference's trainers on the device.
+
+* ``FusedAdamW``            -- ``torch.optim.AdamW`` semantics (decoupled weight decay, bias correction, per-group lr / weight
+  decay: students_teacher.py:27-68, segmentation.py:25-39) with ONE kernel launch per step for all parameter tensors
+  (csrc/proto.hip ``k_adamw_multi``).  It is a ``torch.optim.Optimizer``: ``param_groups`` / ``state_dict`` have AdamW's
+  layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter), so LR schedulers and the reference's checkpoint dicts
+  (``optimizer_state_dict``) interoperate with ``torch.optim.AdamW``.
+* ``WarmupCosineSchedule``  -- modules/utils.py:67-89 (a ``LambdaLR``).
+* ``ema_update_``           -- the teacher's EMA (momentum_model/momentum_model.py:27-36) for all parameters in one launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import _lib as L
+
+_CHUNK = 1024
+
+
+def _chunk_table(sizes: List[int], device) -> torch.Tensor:
+    ids, offs = [], []
+    for t, n in enumerate(sizes):
+        k = (n + _CHUNK - 1) // _CHUNK
+        ids.append(np.full(k, t, np.int32))
+        offs.append(np.arange(k, dtype=np.int32))
+    tab = np.stack([np.concatenate(ids), np.concatenate(offs)], 1).astype(np.int32)
+    return torch.from_numpy(np.ascontiguousarray(tab)).to(device)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > 8:
+            raise ValueError("FusedAdamW supports up to 8 parameter groups")
+        self._plan = None
+
+    def _build(self, entries):
+        dev = entries[0][1].device
+        rows = np.zeros((len(entries), 5), np.int64)
+        for i, (gi, p, st) in enumerate(entries):
+            rows[i] = (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi)
+        if int(L.lib().mivp_sizeof_opt(0)) != 40:
+            raise RuntimeError("AdamTensor layout mismatch")
+        self._plan = {
+            "key": tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr()) for _, p, st in entries),
+            "tensors": torch.from_numpy(rows).to(dev),
+            "chunks": _chunk_table([p.numel() for _, p, _ in entries], dev),
+            "gptr_key": None, "gptr": None,
+        }
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        entries = []
+        hyper = np.zeros((len(self.param_groups), 8), np.float32)
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            step_no = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("FusedAdamW: dense float32 device parameters only")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                step_no = float(st["step"])
+                entries.append((gi, p, st))
+            if step_no is None:
+                step_no = 1.0
+            # all parameters of a group that receive gradients step together (as in the reference's trainers)
+            hyper[gi] = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** step_no,
+                         math.sqrt(1.0 - b2 ** step_no), 0.0)
+        if not entries:
+            return loss
+        key = tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr()) for _, p, st in entries)
+        if self._plan is None or self._plan["key"] != key:
+            self._build(entries)
+        plan = self._plan
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for _, p, _ in entries]
+        for (_, p, _), g in zip(entries, grads):
+            if not p.is_contiguous():
+                raise RuntimeError("FusedAdamW: contiguous parameters only")
+        gkey = tuple(g.data_ptr() for g in grads)
+        if plan["gptr_key"] != gkey:                           # new gradient tensors every backward (set_to_none): 8 B each
+            plan["gptr"] = torch.from_numpy(np.asarray(gkey, np.int64)).to(entries[0][1].device)
+            plan["gptr_key"] = gkey
+        L.call("mivp_adamw_multi", L.ptr(plan["tensors"]), L.ptr(plan["gptr"]), hyper.ctypes.data_as(C.POINTER(C.c_float)),
+               C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), C.c_int32(plan["chunks"].shape[0]), L.stream())
+        return loss
+
+
+class WarmupCosineSchedule(LambdaLR):
+    """modules/utils.py:67-89: linear warm-up over ``warmup_steps`` scheduler steps, then a cosine to zero at ``t_total``."""
+
+    def __init__(self, optimizer, warmup_steps: int, t_total: int, cycles: float = 0.5, last_epoch: int = -1):
+        self.warmup_steps = warmup_steps
+        self.t_total = t_total
+        self.cycles = cycles
+        super().__init__(optimizer, self.lr_lambda, last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        progress = float(step - self.warmup_steps) / float(max(1, self.t_total - self.warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(self.cycles) * 2.0 * progress)))
+
+
+class EmaPlan:
+    """Pointer tables of one (teacher, student) parameter pairing, rebuilt when a storage moves."""
+
+    def __init__(self):
+        self.key = None
+        self.tensors = None
+        self.chunks = None
+
+
+@torch.no_grad()
+def ema_update_(teacher_params, student_params, tau: float, plan: EmaPlan):
+    """teacher = tau * teacher + (1 - tau) * student for every pair, in place, one launch (momentum_model.py:27-36)."""
+    from . import functional as Fn
+    pairs = [(t, s) for t, s in zip(teacher_params, student_params)]
+    if not pairs:
+        return
+    key = tuple((t.data_ptr(), s.data_ptr(), t.numel()) for t, s in pairs)
+    if plan.key != key:
+        for t, s in pairs:
+            if t.dtype != torch.float32 or s.dtype != torch.float32 or not t.is_cuda or t.shape != s.shape \
+                    or not t.is_contiguous() or not s.is_contiguous():
+                raise RuntimeError("ema_update_: contiguous float32 device parameter pairs of equal shape only")
+        rows = np.asarray([(t.data_ptr(), s.data_ptr(), t.numel()) for t, s in pairs], np.int64)
+        dev = pairs[0][0].device
+        plan.tensors = torch.from_numpy(rows).to(dev)
+        plan.chunks = _chunk_table([t.numel() for t, _ in pairs], dev)
+        plan.key = key
+    L.call("mivp_ema_multi", L.ptr(plan.tensors), L.ptr(plan.chunks), C.c_int32(plan.chunks.shape[0]), C.c_float(tau), L.stream())
+    Fn.invalidate_weight_caches()                              # raw in-place writes: no version counter saw them

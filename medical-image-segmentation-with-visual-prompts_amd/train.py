@@ -2,9 +2,10 @@
 ``SegmentationTrainer.train`` (modules/segmentation.py:96-122) on synthetic data, single GPU or one
 process per GPU under ``torch.distributed`` (RCCL).
 
-The loss and optimizer are the "next" rows of SURVEY 8f (N1/N2): they run as stock PyTorch GPU ops
-for now (DiceFocal restated from MONAI's documented formulas -- parity unpinned, see
-oracle/loss_ref.py; ``torch.optim.AdamW(fused=True)``).
+Loss and optimizer: the fused Dice+focal kernel (csrc/loss.hip; DiceFocal restated from MONAI's
+documented formulas -- parity unpinned, see oracle/loss_ref.py), ``optim.FusedAdamW`` (one multi-tensor launch per step),
+and for the ``self_supervised_*`` modes the students/teacher step of students_teacher.py:150-207
+(``mivp_amd.students_teacher``: EMA teacher, two students + teacher forward, ClusteredPrototypeLoss, per-step schedule).
 """
 from __future__ import annotations
 
@@ -57,7 +58,10 @@ def make_conf(workload: str, window=(7, 7, 7), dropout: float = 0.0) -> Tuple[Na
         use_contrastive_learning=False, contrastive_coding_dim=512, output_channels_downstream=2,
         output_channels_pretrain=5, include_background=True, lr_downstream=1e-3, weight_decay_downstream=0.0,
         lr_students_teacher=5e-4, weight_decay_students_teacher=0.1, lr_prompt_tokens=5e-4,
-        weight_decay_prompt_tokens=0.1, **w)
+        weight_decay_prompt_tokens=0.1,
+        # students-teacher trainer (example_configs.yml:84-99)
+        tau=0.99, reduction_factor=4, fwhm=128, k_means_iterations=3, use_prototype_assignment=True, use_real_label=True,
+        warmup_steps_students_teacher=100, t_total_students_teacher=2400, **w)
     return conf, size, batch
 
 
@@ -126,12 +130,13 @@ def build_optimizer(model, conf: Namespace):
     """AdamW over the reference's parameter partition for the mode: ``named_parameters_downstream()`` for
     ``downstream`` (segmentation.py:25-39); decoder(+encoder) and prompt-token groups with their own lr /
     weight decay for the ``*_all`` / ``*_decoder`` modes (students_teacher.py:25-68)."""
+    from .optim import FusedAdamW
     core = model.module if hasattr(model, "module") else model
+    core = core.net_student if hasattr(core, "net_student") else core      # MomentumModel: the student trains
     mode = conf.training_mode
     if mode == "downstream":
         params = [p for _, p in core.named_parameters_downstream()]
-        return torch.optim.AdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream),
-                                 fused=True)
+        return FusedAdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream))
     lr, wd = float(conf.lr_students_teacher), float(conf.weight_decay_students_teacher)
     groups = []
     if mode in ("self_supervised_learning_all", "supervised_learning_all"):
@@ -147,22 +152,30 @@ def build_optimizer(model, conf: Namespace):
     if conf.use_decoder_prompting:
         groups.append({"params": [p for _, p in core.named_parameters_prompt_tokens_decoder()],
                        "lr": float(conf.lr_prompt_tokens), "weight_decay": float(conf.weight_decay_prompt_tokens)})
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=wd, fused=True)
+    return FusedAdamW(groups, lr=lr, weight_decay=wd)
+
+
+def build_scheduler(opt, conf: Namespace):
+    """Per-step WarmupCosineSchedule of the students/teacher trainer (students_teacher.py:69-76,207); the segmentation
+    trainer's per-EPOCH StepLR(100, 0.8) (segmentation.py:34-38) never fires inside a benchmark run."""
+    from .optim import WarmupCosineSchedule
+    if conf.training_mode == "downstream":
+        return None
+    return WarmupCosineSchedule(opt, warmup_steps=int(conf.warmup_steps_students_teacher), t_total=int(conf.t_total_students_teacher))
 
 
 def step_loss(out: dict, conf: Namespace, y) -> torch.Tensor:
-    """The objective the step differentiates.  ``downstream``: DiceFocal on out['downstream'] (segmentation.py:44-50,
-    104-106).  ``supervised_*``: the segmentation term on out['seg_pred'] (students_teacher.py:190-197; the fused
-    Dice+focal kernel stands in for MONAI's DiceLoss).  ``self_supervised_*``: the reference's ClusteredPrototypeLoss
-    is outside the hot path; a mean-square feature objective on out['latent_outputs'] stands in so that
-    the step exercises the same forward/backward."""
+    """The objective of a SINGLE-NETWORK step.  ``downstream``: DiceFocal on out['downstream'] (segmentation.py:44-50,
+    104-106).  ``supervised_*``: the segmentation term alone on out['seg_pred'] (students_teacher.py:190-197; this is the
+    ``sup_all`` throughput workload -- the full supervised step with its prototype term is
+    ``students_teacher.students_teacher_step``).  The ``self_supervised_*`` modes have no single-network objective: their
+    step is the students/teacher step."""
     mode = conf.training_mode
     if mode == "downstream":
         return dice_focal_loss(out["downstream"], y, conf.include_background, 4.0)
     if mode in ("supervised_learning_all", "supervised_learning_decoder"):
         return dice_focal_loss(out["seg_pred"], y, conf.include_background, 4.0)
-    lat = out["latent_outputs"]
-    return (lat.float() ** 2).mean()
+    raise ValueError(f"{mode}: use mivp_amd.students_teacher.students_teacher_step (students_teacher.py:150-207)")
 
 
 def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
@@ -213,12 +226,13 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
-def wrap_ddp(model, local_rank: Optional[int]):
+def wrap_ddp(model, local_rank: Optional[int], gloo: bool = False):
     """One process per GPU, gradient all-reduce (mean) overlapped with backward through DDP buckets
     (RCCL over xGMI on the GPU box).  BatchNorm statistics stay per replica as in the single-device
-    reference: no buffer broadcast, no SyncBN.  ``local_rank=None`` wraps a CPU module (gloo tests)."""
+    reference: no buffer broadcast, no SyncBN.  ``local_rank=None`` wraps a CPU module (gloo tests);
+    ``gloo=True``: a device module over a gloo group (several ranks may share one GPU: device_ids must stay unset)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    if local_rank is None:
+    if local_rank is None or gloo:
         return DDP(model, broadcast_buffers=False, gradient_as_bucket_view=True)
     return DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
                gradient_as_bucket_view=True)

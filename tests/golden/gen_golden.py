@@ -9,6 +9,11 @@ are imported through a synthetic parent package that skips
     refmodules.swin_transformer.{swin_block,down}
     refmodules.multi_head_attention.{window_attention,relative_positional_encoding}
 
+    refmodules.losses.clustered_prototype_loss, refmodules.momentum_model            (G8: students/teacher step)
+    refmodules.utils  (G9: MeanIoU, DiceCoefficient, WarmupCosineSchedule, map_label_indices; the file imports cv2 at
+                       the top for its PNG viewers only, so an EMPTY placeholder module named cv2 is registered first --
+                       no cv2 function is ever called by the four symbols captured here)
+
 ``swin_unetr/unet_blocks.py`` and ``swin_unetr/swin_unetr.py`` import three MONAI
 factories.  For those two files only, a 3-symbol stand-in (``_monai_standin``,
 own code) maps the factories to the stock torch modules MONAI resolves them to
@@ -312,9 +317,144 @@ def gen_unetr(su):
             "note": "MONAI stand-in used: parity unpinned at the MONAI boundary"})
 
 
+def coord_grid(shape):
+    """datasets/transforms.py:336-344 ``get_coord_grid`` for a [C, H, W, D] image shape (restated: that file imports MONAI)."""
+    g = torch.stack(torch.meshgrid(torch.arange(shape[1]), torch.arange(shape[2]), torch.arange(shape[3]), indexing="ij"), 0).float()
+    return g - torch.tensor([(shape[1] - 1) / 2., (shape[2] - 1) / 2., (shape[3] - 1) / 2.]).reshape(3, 1, 1, 1)
+
+
+def gen_prototype_loss():
+    """G8: ClusteredPrototypeLoss (losses/clustered_prototype_loss.py:13-206) forward + input gradients.  The student crops
+    are sub-volumes of the teacher volume (their coordinate grids are crops of the teacher's), as the data pipeline makes
+    them; the spatial jitter comes from torch's global RNG, so it is re-drawn here with the same seed and stored."""
+    import math
+    from refmodules.losses import ClusteredPrototypeLoss
+    cases = {
+        # name: (teacher dims, [student crop slices], channels, reduction_factor, fwhm, k-means iterations, temp_s, temp_t)
+        "proto_a": ((16, 16, 8), [((2, 14), (1, 13), (0, 8)), ((0, 16), (0, 16), (0, 8))], 8, 4.0, 128.0, 3, 0.066, 0.033),
+        "proto_b": ((12, 20, 12), [((0, 8), (4, 20), (2, 12)), ((3, 12), (0, 16), (0, 12))], 6, 2.0, 16.0, 2, 0.1, 0.05),
+        "proto_c": ((24, 24, 16), [((0, 24), (0, 24), (0, 16)), ((4, 20), (4, 20), (2, 14))], 8, 4.0, 128.0, 3, 0.066, 0.033),
+    }
+    for name, (tdims, crops, C, red, fwhm, iters, ts, tt) in cases.items():
+        gen = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+        B = 2
+        emb_t = torch.randn(B, C, *tdims, generator=gen).requires_grad_(True)
+        coord_t = coord_grid((1,) + tdims)[None].repeat(B, 1, 1, 1, 1)
+        emb_s, coord_s = [], []
+        for cr in crops:
+            sl = tuple(slice(a, b) for a, b in cr)
+            dims = tuple(b - a for a, b in cr)
+            emb_s.append(torch.randn(B, C, *dims, generator=gen).requires_grad_(True))
+            coord_s.append(coord_t[(slice(None), slice(None)) + sl].clone())
+        loss_fn = ClusteredPrototypeLoss(reduction_factor=red, k_means_iterations=iters, fwhm=fwhm)
+        seed = 1000 + len(name)
+        torch.manual_seed(seed)
+        jit = [torch.randint(low=0, high=int(math.ceil(red)), size=(6,)) for _ in crops]      # the draws the loss makes
+        torch.manual_seed(seed)
+        loss = loss_fn(emb_s, emb_t, coord_s, coord_t, temp_s=ts, temp_t=tt)
+        loss.backward()
+        arrays = {"in/emb_t": emb_t, "in/coord_t": coord_t, "out/loss": loss.reshape(1), "grad/emb_t": emb_t.grad}
+        for i in range(len(crops)):
+            arrays[f"in/emb_s{i}"] = emb_s[i]
+            arrays[f"in/coord_s{i}"] = coord_s[i]
+            arrays[f"in/jitter{i}"] = jit[i]
+            arrays[f"grad/emb_s{i}"] = emb_s[i].grad
+        _save(name, arrays, {"reduction_factor": red, "fwhm": fwhm, "k_means_iterations": iters, "temp_s": ts, "temp_t": tt,
+                             "n_students": len(crops)})
+
+
+def gen_momentum():
+    """G8: MomentumModel (momentum_model/momentum_model.py:4-36) with a toy architecture: construction from
+    ``architecture(conf=conf)``, ``copy_state_dict`` and two EMA steps of ``update_teacher``."""
+    from refmodules.momentum_model import MomentumModel
+
+    class Toy(torch.nn.Module):
+        def __init__(self, conf):
+            super().__init__()
+            self.a = torch.nn.Linear(5, 7)
+            self.b = torch.nn.Conv3d(2, 3, 3)
+            self.n = torch.nn.BatchNorm3d(3)
+
+        def forward(self, x):
+            return {"latent_outputs": x}
+
+    torch.manual_seed(77)
+    mm = MomentumModel(Namespace(tau=0.99), Toy)
+    arrays = {}
+    for k, v in mm.net_student.named_parameters():
+        arrays[f"student0/{k}"] = v.detach().clone()
+    for k, v in mm.net_teacher.named_parameters():
+        arrays[f"teacher0/{k}"] = v.detach().clone()
+    mm.update_teacher()
+    for k, v in mm.net_teacher.named_parameters():
+        arrays[f"teacher1/{k}"] = v.detach().clone()
+    with torch.no_grad():
+        for q in mm.net_student.parameters():
+            q.add_(0.05 * torch.randn(q.shape))
+    for k, v in mm.net_student.named_parameters():
+        arrays[f"student1/{k}"] = v.detach().clone()
+    mm.update_teacher()
+    for k, v in mm.net_teacher.named_parameters():
+        arrays[f"teacher2/{k}"] = v.detach().clone()
+    mm.copy_state_dict()
+    copied = all(torch.equal(a, b) for a, b in zip(mm.net_student.parameters(), mm.net_teacher.parameters()))
+    frozen = all(not q.requires_grad for q in mm.net_teacher.parameters())
+    outs, outt = mm([torch.ones(1), torch.zeros(1)], torch.full((1,), 2.0))
+    _save("momentum_model", arrays, {"tau": 0.99, "copy_state_dict_copies": copied, "copy_state_dict_freezes_teacher": frozen,
+                                     "forward_returns": [len(outs), sorted(outt.keys())],
+                                     "param_order": [k for k, _ in mm.net_student.named_parameters()]})
+
+
+def gen_utils():
+    """G9: metrics / schedule / label mapping of modules/utils.py:14-89,372-388 (the reference's own code, see the module
+    docstring for the empty cv2 placeholder)."""
+    if "cv2" not in sys.modules:
+        try:
+            import cv2  # noqa: F401
+        except ImportError:
+            sys.modules["cv2"] = types.ModuleType("cv2")
+    from refmodules import utils as U
+    gen = torch.Generator().manual_seed(21)
+    arrays, meta = {}, {}
+    # metrics: two update() calls, then compute()
+    for ncls in (2, 5):
+        miou, dice = U.MeanIoU(ncls), U.DiceCoefficient(ncls)
+        for step in range(2):
+            preds = torch.randn(2, ncls, 6, 5, 4, generator=gen)
+            target = torch.randint(0, ncls, (2, 1, 6, 5, 4), generator=gen).float()
+            miou.update(preds, target)
+            dice.update(preds, target)
+            arrays[f"metrics{ncls}/preds{step}"] = preds
+            arrays[f"metrics{ncls}/target{step}"] = target
+        arrays[f"metrics{ncls}/miou"] = miou.compute().reshape(1)
+        arrays[f"metrics{ncls}/dice"] = dice.compute().reshape(1)
+    # schedule: the lr of both groups over 40 scheduler steps
+    p1, p2 = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.AdamW([{"params": [p1], "lr": 5e-4}, {"params": [p2], "lr": 1e-3}], lr=5e-4)
+    sched = U.WarmupCosineSchedule(opt, warmup_steps=10, t_total=30)
+    lrs = []
+    for _ in range(40):
+        lrs.append([g["lr"] for g in opt.param_groups])
+        opt.step()
+        sched.step()
+    arrays["sched/lrs"] = torch.tensor(lrs, dtype=torch.float64)
+    meta["sched"] = {"warmup_steps": 10, "t_total": 30, "base_lrs": [5e-4, 1e-3]}
+    # label mapping (the yml's active_labels_pretrain / _downstream)
+    masks = torch.randint(0, 7, (2, 1, 5, 4, 3), generator=gen).float()
+    arrays["labels/in"] = masks.clone()
+    arrays["labels/pretrain"] = U.map_label_indices(masks.clone(), [0, 1, 2, 3, 5])
+    arrays["labels/downstream"] = U.map_label_indices(masks.clone(), [5, 0])
+    _save("utils_metrics_schedule", arrays, meta)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     sb, down, wa, rpe, ub, su = _import_reference()
+    if "--only-g8g9" in sys.argv:
+        gen_prototype_loss()
+        gen_momentum()
+        gen_utils()
+        sys.exit(0)
     gen_relpe(rpe)
     gen_mask(sb)
     gen_attention(wa)
@@ -322,3 +462,6 @@ if __name__ == "__main__":
     gen_merge(down)
     gen_upblock(ub)
     gen_unetr(su)
+    gen_prototype_loss()
+    gen_momentum()
+    gen_utils()

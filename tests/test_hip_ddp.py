@@ -101,3 +101,44 @@ def test_two_ranks_one_gpu(case):
     assert par0.keys() == par1.keys() and len(par0) > 0
     for k in par0:
         assert np.array_equal(par0[k], par1[k]), k                 # replicas identical after three steps
+
+
+def _bench_rank(rank, world, port, q):
+    """One rank of ``bench.py --gpus 2 --backend gloo`` as a child process, stdout captured."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--device", "0",
+                        "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    q.put((rank, r.returncode, r.stdout, r.stderr[-2000:]))
+
+
+def test_bench_multi_rank_control_flow_over_gloo():
+    """bench.py's N > 1 path end to end: torch.distributed env rendezvous, DDP-wrapped HIP model, fixed
+    settle count, barrier + synchronize around the timed steps, max-over-ranks timing, ONE JSON line from rank 0 only,
+    destroy_process_group -- with two ranks sharing the test box's single GPU over gloo (RCCL refuses two ranks per device)."""
+    import json
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, rc, out, err = q.get(timeout=900)
+        res[rank] = (rc, out, err)
+    for p in procs:
+        p.join(60)
+    assert res[0][0] == 0 and res[1][0] == 0, (res[0][2], res[1][2])
+    assert not [ln for ln in res[1][1].splitlines() if ln.lstrip().startswith("{")]      # only rank 0 reports (gloo itself prints a connection note on stdout)
+    lines = [ln for ln in res[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "volumes/s"
+    assert d["config"]["global_batch"] == 2 * 2 and d["config"]["parallelism"] == "dp2" and d["config"]["backend"] == "gloo"
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline_attention"] is not None

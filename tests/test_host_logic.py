@@ -48,3 +48,39 @@ def test_bn_momentum_none_is_cumulative_average():
     bn.num_batches_tracked += 3
     assert Fn.bn_momentum(bn) == 0.25
     assert Fn.bn_momentum(torch.nn.BatchNorm3d(4)) == 0.1
+
+
+def test_reference_momentum_model_accepts_the_product_class():
+    """Drop-in: the REFERENCE's MomentumModel (momentum_model/momentum_model.py:4-36) builds two product SwinUnetR instances
+    through ``architecture(conf=conf)`` and pairs their parameters by zip order.  Runs where /root/reference is mounted (the
+    build container); construction, the EMA update and copy_state_dict need no GPU."""
+    import os
+    import sys
+    import types
+    import pytest
+    ref = "/root/reference/src/modules"
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted")
+    import mivp_amd
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    if "refmodules" not in sys.modules:
+        parent = types.ModuleType("refmodules")
+        parent.__path__ = [ref]
+        sys.modules["refmodules"] = parent
+    from refmodules.momentum_model import MomentumModel
+    conf, _, _ = train.make_conf("tiny")
+    conf.training_mode = "self_supervised_learning_all"
+    mm = MomentumModel(conf, SwinUnetR)
+    names_s = [k for k, _ in mm.net_student.named_parameters()]
+    assert names_s == [k for k, _ in mm.net_teacher.named_parameters()] and len(names_s) > 200
+    t0 = [p.detach().clone() for p in mm.net_teacher.parameters()]
+    mm.update_teacher()
+    for a, t, s in zip(t0, mm.net_teacher.parameters(), mm.net_student.parameters()):
+        assert torch.allclose(t, conf.tau * a + (1 - conf.tau) * s.detach())
+    mm.copy_state_dict()
+    assert all(torch.equal(a, b) for a, b in zip(mm.net_student.parameters(), mm.net_teacher.parameters()))
+    # the optimizer recipe of the reference's trainer (students_teacher.py:27-68) resolves against the product's helpers
+    n = (sum(p.numel() for _, p in mm.net_student.named_parameters_decoder())
+         + sum(p.numel() for _, p in mm.net_student.named_parameters_encoder()))
+    assert n > 0

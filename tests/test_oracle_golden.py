@@ -197,3 +197,76 @@ def test_rounding_aware_option_stays_near_the_pinned_path(tag):
     assert torch.equal(y1, r(y1))                              # the block output is a stored bf16 tensor
     assert 1e-4 < rel_l2(y1, y0) < 6e-3
     assert rel_l2(dx1, dx0) < 1.5e-2 and rel_l2(dp1, dp0) < 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------------
+# G8 / G9: students-teacher objective, EMA, schedule, metrics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["proto_a", "proto_b", "proto_c"])
+def test_clustered_prototype_loss(tag):
+    """oracle/proto_ref.py against ClusteredPrototypeLoss run by the reference (value and every input gradient)."""
+    from oracle import proto_ref as P
+    fx = load_fixture(tag)
+    m = fx.meta
+    n = m["n_students"]
+    emb_t = fx["in"]["emb_t"].clone().requires_grad_(True)
+    emb_s = [fx["in"][f"emb_s{i}"].clone().requires_grad_(True) for i in range(n)]
+    loss = P.clustered_prototype_loss(
+        emb_s, emb_t, [fx["in"][f"coord_s{i}"] for i in range(n)], fx["in"]["coord_t"],
+        [fx["in"][f"jitter{i}"].tolist() for i in range(n)], m["reduction_factor"], m["k_means_iterations"], m["fwhm"],
+        m["temp_s"], m["temp_t"])
+    assert abs(float(loss) - float(fx["out"]["loss"])) < 2e-5 * max(1.0, abs(float(fx["out"]["loss"])))
+    loss.backward()
+    assert rel_l2(emb_t.grad, fx["grad"]["emb_t"]) < 2e-4
+    for i in range(n):
+        assert rel_l2(emb_s[i].grad, fx["grad"][f"emb_s{i}"]) < 2e-4, i
+
+
+def test_coord_grid_and_sampling_match_grid_sample():
+    """The index-form sampler equals affine_grid + grid_sample (the reference's formulation) on random volumes, and the
+    coordinate grid is the one the fixtures carry."""
+    import torch.nn.functional as F
+    from oracle import proto_ref as P
+    fx = load_fixture("proto_b")
+    assert torch.equal(P.coord_grid(fx["in"]["coord_t"].shape[2:]), fx["in"]["coord_t"][0])
+    g = torch.Generator().manual_seed(4)
+    for dims, rf in (((12, 20, 12), 2.0), ((16, 16, 8), 4.0), ((9, 7, 5), 3.0), ((6, 6, 6), 8.0)):
+        vol = torch.randn(2, 3, *dims, generator=g)
+        rs = P.reduced_size(dims, rf)
+        theta = torch.tensor([[1., 0, 0, 0], [0, 1., 0, 0], [0, 0, 1., 0]]).unsqueeze(0)
+        aff = F.affine_grid(theta, [1, 1, *rs], align_corners=False).expand(2, -1, -1, -1, -1)
+        want = F.grid_sample(vol, aff, mode="bilinear", padding_mode="reflection", align_corners=False)
+        assert torch.allclose(P.sample_volume(vol, rs), want, atol=1e-5), (dims, rf)
+
+
+def test_momentum_model_ema():
+    from oracle import proto_ref as P
+    fx = load_fixture("momentum_model")
+    tau = fx.meta["tau"]
+    assert fx.meta["copy_state_dict_copies"] and fx.meta["copy_state_dict_freezes_teacher"]
+    for k in fx.meta["param_order"]:
+        t1 = P.ema_update(fx["teacher0"][k], fx["student0"][k], tau)
+        assert torch.allclose(t1, fx["teacher1"][k], rtol=1e-6, atol=1e-7), k
+        t2 = P.ema_update(fx["teacher1"][k], fx["student1"][k], tau)
+        assert torch.allclose(t2, fx["teacher2"][k], rtol=1e-6, atol=1e-7), k
+
+
+def test_schedule_metrics_and_label_mapping():
+    from oracle import proto_ref as P
+    from oracle.loss_ref import dice_coefficient, mean_iou
+    fx = load_fixture("utils_metrics_schedule")
+    sc = fx.meta["sched"]
+    lrs = fx["sched"]["lrs"]
+    for step in range(lrs.shape[0]):
+        f = P.warmup_cosine_factor(step, sc["warmup_steps"], sc["t_total"])
+        for gi, base in enumerate(sc["base_lrs"]):
+            assert abs(float(lrs[step, gi]) - base * f) < 1e-12, (step, gi)
+    for ncls in (2, 5):
+        grp = fx[f"metrics{ncls}"]
+        # the reference accumulates counts over update() calls: concatenating the batches is the same thing
+        preds = torch.cat([grp["preds0"], grp["preds1"]], 0)
+        target = torch.cat([grp["target0"], grp["target1"]], 0)
+        assert abs(float(mean_iou(preds, target, ncls)) - float(grp["miou"])) < 1e-6
+        assert abs(float(dice_coefficient(preds, target, ncls)) - float(grp["dice"])) < 1e-6
+    assert torch.equal(P.map_label_indices(fx["labels"]["in"], [0, 1, 2, 3, 5]), fx["labels"]["pretrain"])
+    assert torch.equal(P.map_label_indices(fx["labels"]["in"], [5, 0]), fx["labels"]["downstream"])
