@@ -486,11 +486,13 @@ int mivp_sample_points_bwd(const float* gout, int32_t B, int32_t H, int32_t W, i
                            const int32_t* const* i1, const int32_t* const* i2, const float* const* w1, const float* const* w2,
                            void* gvol, mivp_stream_t stream);
 /* torch.optim.AdamW over many tensors in one launch (students_teacher.py:27-68, segmentation.py:25-39).
- * tensors: device array of {float* p, float* exp_avg, float* exp_avg_sq, int64 n, int32 group, int32 pad} (40 bytes);
- * grads: device array of float* (same order); groups: HOST array [n_groups][8] f32 = {lr, beta1, beta2, eps, weight_decay,
- * 1 - beta1^step, sqrt(1 - beta2^step), 0}; chunks: device int32 [n_chunks][2] = (tensor index, 1024-element chunk). */
-int mivp_adamw_multi(const void* tensors, const void* grads, const float* groups, int32_t n_groups, const void* chunks,
-                     int32_t n_chunks, mivp_stream_t stream);
+ * tensors: device array of {float* p, float* exp_avg, float* exp_avg_sq, int64 n, int32 group, int32 pad} (40 bytes), static
+ * across steps; grads: HOST array of n_tensors device pointers (they change every backward and travel as kernel arguments,
+ * 384 per launch); chunk_begin: HOST int32 [n_tensors + 1], first chunk of each tensor; groups: HOST [n_groups][8] f32 =
+ * {lr, beta1, beta2, eps, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step), 0}; chunks: device int32 [.][2] = (tensor
+ * index, 1024-element chunk), tensor-major. */
+int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                     const float* groups, int32_t n_groups, const void* chunks, mivp_stream_t stream);
 /* EMA teacher update (momentum_model.py:27-36): tensors = device array of {float* teacher, const float* student, int64 n} */
 int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream);
 int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2: EMA record */

@@ -141,14 +141,16 @@ struct AdamTensor {             // 40 bytes; static across steps (the gradient p
 };
 struct AdamGroup { float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, pad; };   // bias corrections precomputed per step
 struct AdamGroups { AdamGroup g[8]; };                          // by value in the kernel arguments: no per-step upload
+constexpr int ADAM_GRADS_PER_LAUNCH = 384;
+struct AdamGrads { const float* g[ADAM_GRADS_PER_LAUNCH]; };    // gradient pointers change every backward: kernel arguments too
 
 constexpr int OPT_CHUNK = 1024;
 
-__global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restrict__ tensors, const float* const* __restrict__ grads,
+__global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restrict__ tensors, AdamGrads grads, int grad_base,
                                                      AdamGroups groups, const int2* __restrict__ chunks) {
     const int2 ck = chunks[blockIdx.x];
     const AdamTensor t = tensors[ck.x];
-    const float* __restrict__ tg = grads[ck.x];
+    const float* __restrict__ tg = grads.g[ck.x - grad_base];
     const AdamGroup h = groups.g[t.group];
     const long base = (long)ck.y * OPT_CHUNK;
     // torch.optim.AdamW (single-tensor formulas, same operation order, so the result is bit-equal on f32):
@@ -187,16 +189,24 @@ __global__ __launch_bounds__(256) void k_ema_multi(const EmaTensor* __restrict__
 
 }  // namespace
 
-extern "C" int mivp_adamw_multi(const void* tensors, const void* grads, const float* groups, int32_t n_groups, const void* chunks,
-                                int32_t n_chunks, mivp_stream_t stream) {
-    MIVP_REQUIRE(tensors && grads && groups && chunks && n_chunks > 0 && n_groups >= 1 && n_groups <= 8);
+extern "C" int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                                const float* groups, int32_t n_groups, const void* chunks, mivp_stream_t stream) {
+    MIVP_REQUIRE(tensors && grads && groups && chunks && chunk_begin && n_tensors > 0 && n_groups >= 1 && n_groups <= 8);
     AdamGroups gs;
     for (int i = 0; i < 8; ++i) {
         const float* src = groups + 8 * (i < n_groups ? i : 0);
         gs.g[i] = AdamGroup{src[0], src[1], src[2], src[3], src[4], src[5], src[6], 0.f};
     }
-    hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)tensors,
-                       (const float* const*)grads, gs, (const int2*)chunks);
+    // gradient pointers and hyper-parameters travel as kernel arguments (HOST arrays here): nothing is uploaded per step
+    for (int base = 0; base < n_tensors; base += ADAM_GRADS_PER_LAUNCH) {
+        const int cnt = n_tensors - base < ADAM_GRADS_PER_LAUNCH ? n_tensors - base : ADAM_GRADS_PER_LAUNCH;
+        AdamGrads gp;
+        for (int i = 0; i < ADAM_GRADS_PER_LAUNCH; ++i) gp.g[i] = (const float*)grads[base + (i < cnt ? i : 0)];
+        const int c0 = chunk_begin[base], c1 = chunk_begin[base + cnt];
+        if (c1 <= c0) continue;
+        hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)tensors,
+                           gp, base, gs, (const int2*)chunks + c0);
+    }
     return mivp_check_launch("adamw_multi");
 }
 

@@ -280,7 +280,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
     // quarter of the CU's 160 KB at 7^3 windows, i.e. three workgroups per CU instead of four
     uint8_t* ridk = reinterpret_cast<uint8_t*>(Vt + (size_t)(16 * DVT) * VROW);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the query-tile loop and its addresses stay in SGPRs
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, heads = d.heads, hd = C / heads;
     const long bph = blockIdx.x;                             // (b*P + pw)*heads + head

@@ -132,39 +132,51 @@ __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Y[tap][t][co] (fp16) = sum_c Wf[tap*Cout + co][c] * x[t][c] + Wf[..][C] * 1     (K = C + 1 <= 64, M = 27*Cout <= 16*MT)
 // ---------------------------------------------------------------------------------------------
+constexpr int TAPS_TILES = 8;                                   // 16-token tiles per wave: the folded weights stay in registers
+
 template <int MT, int COUT>
 __global__ __launch_bounds__(256) void k_uphead_taps(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf, long T, int C,
                                                      _Float16* __restrict__ Y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
-    const bool live = t < T;
-    bf16x8 xb[2];
+    // folded weights as a bf16 hi + lo pair: a single bf16 rounding of w * scale is a systematic 2^-9 error per weight
+    // (1.7e-3 of the logits, same sign for every voxel: it biased the arg-max near class boundaries).  Loaded ONCE per
+    // wave and reused for TAPS_TILES token tiles (per-tile reloads made the kernel weight-fetch-bound: 16 KB per 16 tokens).
+    bf16x8 wh[MT][2], wl[MT][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int c = 32 * s + 8 * g;
-        bf16x8 v = zero8();
-        if (live) {
-            if (c + 8 <= C) v = ld8(x + t * C + c);
-            else if (c == C) v[0] = (bf16_t)1.0f;              // the constant-one channel (C % 8 == 0)
-        }
-        xb[s] = v;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        f32x4 acc = fzero4();
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            // folded weights as a bf16 hi + lo pair: a single bf16 rounding of w * scale is a systematic 2^-9 error per
-            // weight (1.7e-3 of the logits, same sign for every voxel: it biased the arg-max near class boundaries)
-            acc = mfma16(ld8(wf + (long)(16 * mt + r) * 64 + 32 * s + 8 * g), xb[s], acc);
-            acc = mfma16(ld8(wf + (long)(16 * (MT + mt) + r) * 64 + 32 * s + 8 * g), xb[s], acc);
+            wh[mt][s] = ld8(wf + (long)(16 * mt + r) * 64 + 32 * s + 8 * g);
+            wl[mt][s] = ld8(wf + (long)(16 * (MT + mt) + r) * 64 + 32 * s + 8 * g);
         }
-        if (live) {
+    const long tile0 = ((long)blockIdx.x * 4 + wave) * TAPS_TILES;
+#pragma unroll 2
+    for (int it = 0; it < TAPS_TILES; ++it) {
+        const long t = (tile0 + it) * 16 + r;
+        const bool live = t < T;
+        bf16x8 xb[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = 16 * mt + 4 * g + j;
-                if (m < 27 * COUT) Y[((long)(m / COUT) * T + t) * COUT + (m % COUT)] = (_Float16)acc[j];
+        for (int s = 0; s < 2; ++s) {
+            const int c = 32 * s + 8 * g;
+            bf16x8 v = zero8();
+            if (live) {
+                if (c + 8 <= C) v = ld8(x + t * C + c);
+                else if (c == C) v[0] = (bf16_t)1.0f;          // the constant-one channel (C % 8 == 0)
+            }
+            xb[s] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 acc = fzero4();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { acc = mfma16(wh[mt][s], xb[s], acc); acc = mfma16(wl[mt][s], xb[s], acc); }
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 16 * mt + 4 * g + j;
+                    if (m < 27 * COUT) Y[((long)(m / COUT) * T + t) * COUT + (m % COUT)] = (_Float16)acc[j];
+                }
             }
         }
     }
@@ -758,7 +770,7 @@ extern "C" int mivp_uphead_fwd(const void* x, const void* wf, const float* bias,
     const long T = (long)B * h * w * d;
     hipStream_t st = (hipStream_t)stream;
     _Float16* Y = (_Float16*)workspace;
-    const unsigned g1 = (unsigned)((T + 63) / 64), g2 = (unsigned)((T + 255) / 256);
+    const unsigned g1 = (unsigned)((T + 64 * TAPS_TILES - 1) / (64 * TAPS_TILES)), g2 = (unsigned)((T + 255) / 256);
 #define UP_FWD(MT, CO)                                                                                             \
     do {                                                                                                           \
         hipLaunchKernelGGL((k_uphead_taps<MT, CO>), dim3(g1), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, T, (int)C, Y); \

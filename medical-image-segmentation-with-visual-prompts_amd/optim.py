@@ -23,14 +23,16 @@ from . import _lib as L
 _CHUNK = 1024
 
 
-def _chunk_table(sizes: List[int], device) -> torch.Tensor:
-    ids, offs = [], []
+def _chunk_table(sizes: List[int], device, with_begin: bool = False):
+    ids, offs, begin = [], [], [0]
     for t, n in enumerate(sizes):
         k = (n + _CHUNK - 1) // _CHUNK
         ids.append(np.full(k, t, np.int32))
         offs.append(np.arange(k, dtype=np.int32))
+        begin.append(begin[-1] + k)
     tab = np.stack([np.concatenate(ids), np.concatenate(offs)], 1).astype(np.int32)
-    return torch.from_numpy(np.ascontiguousarray(tab)).to(device)
+    dev_tab = torch.from_numpy(np.ascontiguousarray(tab)).to(device)
+    return (dev_tab, np.asarray(begin, np.int32)) if with_begin else dev_tab
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -40,6 +42,19 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(self.param_groups) > 8:
             raise ValueError("FusedAdamW supports up to 8 parameter groups")
         self._plan = None
+        self._steps = {}          # id(param) -> step count as a Python int (the state's ``step`` tensors are synced lazily)
+
+    def state_dict(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) in self._steps and p in self.state:
+                    self.state[p]["step"] = torch.tensor(float(self._steps[id(p)]), dtype=torch.float32)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._steps = {id(p): int(float(st["step"])) for p, st in self.state.items() if "step" in st}
+        self._plan = None
 
     def _build(self, entries):
         dev = entries[0][1].device
@@ -48,11 +63,10 @@ class FusedAdamW(torch.optim.Optimizer):
             rows[i] = (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi)
         if int(L.lib().mivp_sizeof_opt(0)) != 40:
             raise RuntimeError("AdamTensor layout mismatch")
+        chunks, begin = _chunk_table([p.numel() for _, p, _ in entries], dev, with_begin=True)
         self._plan = {
             "key": tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr()) for _, p, st in entries),
-            "tensors": torch.from_numpy(rows).to(dev),
-            "chunks": _chunk_table([p.numel() for _, p, _ in entries], dev),
-            "gptr_key": None, "gptr": None,
+            "tensors": torch.from_numpy(rows).to(dev), "chunks": chunks, "begin": begin,
         }
 
     @torch.no_grad()
@@ -76,8 +90,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                step_no = float(st["step"])
+                n = self._steps.get(id(p), 0) + 1
+                self._steps[id(p)] = n
+                step_no = float(n)
                 entries.append((gi, p, st))
             if step_no is None:
                 step_no = 1.0
@@ -94,12 +109,12 @@ class FusedAdamW(torch.optim.Optimizer):
         for (_, p, _), g in zip(entries, grads):
             if not p.is_contiguous():
                 raise RuntimeError("FusedAdamW: contiguous parameters only")
-        gkey = tuple(g.data_ptr() for g in grads)
-        if plan["gptr_key"] != gkey:                           # new gradient tensors every backward (set_to_none): 8 B each
-            plan["gptr"] = torch.from_numpy(np.asarray(gkey, np.int64)).to(entries[0][1].device)
-            plan["gptr_key"] = gkey
-        L.call("mivp_adamw_multi", L.ptr(plan["tensors"]), L.ptr(plan["gptr"]), hyper.ctypes.data_as(C.POINTER(C.c_float)),
-               C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), C.c_int32(plan["chunks"].shape[0]), L.stream())
+        # the gradient tensors are new every backward (zero_grad(set_to_none=True)): their pointers go to the kernel as
+        # arguments (a host array here) -- an upload per step would be a synchronous pageable copy that stalls the launch queue
+        gptr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        L.call("mivp_adamw_multi", L.ptr(plan["tensors"]), gptr, C.c_int32(len(grads)),
+               plan["begin"].ctypes.data_as(C.POINTER(C.c_int32)), hyper.ctypes.data_as(C.POINTER(C.c_float)),
+               C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), L.stream())
         return loss
 
 
