@@ -497,6 +497,12 @@ int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_te
 int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream);
 int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2: EMA record */
 
+/* Per-class counts of arg-max(logits) against a label volume (modules/utils.py:14-64 MeanIoU / DiceCoefficient without
+ * host round trips): counts int64 [C][3] += (|pred = c and target = c|, |pred = c|, |target = c|); logits f32 [B][vol][C]
+ * (channels_last) or [B][C][vol], target f32 [B][vol] class indices, nvox = B * vol, C <= 16. */
+int mivp_seg_counts(const float* logits, const float* target, int64_t nvox, int32_t C, int32_t channels_last, int64_t vol,
+                    void* counts, mivp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

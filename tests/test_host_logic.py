@@ -84,3 +84,70 @@ def test_reference_momentum_model_accepts_the_product_class():
     n = (sum(p.numel() for _, p in mm.net_student.named_parameters_decoder())
          + sum(p.numel() for _, p in mm.net_student.named_parameters_encoder()))
     assert n > 0
+
+
+def test_checkpoint_wire_format_round_trip(tmp_path):
+    """The reference's checkpoint dict (segmentation.py:145-154, students_teacher.py:234-244): keys, file name, epoch + 1,
+    safe loading, and interchange of the optimizer state with torch.optim.AdamW (CPU: the model is only a state holder)."""
+    import mivp_amd
+    from mivp_amd import checkpoint as CK, train
+    from mivp_amd.optim import WarmupCosineSchedule
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, _, _ = train.make_conf("tiny")
+    torch.manual_seed(0)
+    model, teacher = SwinUnetR(conf), SwinUnetR(conf)
+    params = [p for _, p in model.named_parameters_downstream()]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    for p in params:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    sched = WarmupCosineSchedule(opt, 5, 50)
+    sched.step()
+    path = CK.save_checkpoint(tmp_path, 19, model, opt, sched, teacher=teacher)
+    assert path.endswith("0019.pt")
+    ck = CK.read_checkpoint(path)
+    assert list(ck) == ["current_epoch", "model_state_dict", "teacher_state_dict", "optimizer_state_dict", "scheduler_state_dict"]
+    assert ck["current_epoch"] == 20
+    assert list(ck["model_state_dict"]) == list(model.state_dict())
+    m2, t2 = SwinUnetR(conf), SwinUnetR(conf)
+    p2 = [p for _, p in m2.named_parameters_downstream()]
+    o2 = torch.optim.AdamW(p2, lr=1e-3)
+    s2 = WarmupCosineSchedule(o2, 5, 50)
+    assert CK.resume(path, m2, o2, s2, teacher=t2) == 20
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert all(torch.equal(a, b) for a, b in zip(teacher.state_dict().values(), t2.state_dict().values()))
+    assert o2.state_dict()["state"][0]["exp_avg"].equal(opt.state_dict()["state"][0]["exp_avg"])
+    assert s2.last_epoch == sched.last_epoch and o2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    # backbone load into a model with different prompting flags: the matching entries really arrive (the reference's
+    # own code writes into a copy of state_dict() and loads nothing: SURVEY Appendix F)
+    conf3, _, _ = train.make_conf("cfg1")
+    conf3.hidden_channels, conf3.num_heads_encoder, conf3.num_heads_decoder = conf.hidden_channels, conf.num_heads_encoder, conf.num_heads_decoder
+    m3 = SwinUnetR(conf3)
+    n = CK.load_backbone(path, m3)
+    assert 0 < n < len(model.state_dict())
+    assert torch.equal(m3.state_dict()["bottleneck.weight"], model.state_dict()["bottleneck.weight"])
+
+
+def test_sliding_window_grid_matches_the_reference_formulation():
+    """inference.sliding_windows against the unfold chain of segmentation.py:232-253 written out on the CPU, incl. volumes
+    the stride grid does not cover exactly (centre crop) and the window order."""
+    import mivp_amd
+    from mivp_amd import inference as I
+    g = torch.Generator().manual_seed(1)
+    for size, roi in (((20, 17, 9), (8, 8, 4)), ((16, 16, 8), (8, 8, 8)), ((13, 30, 11), (6, 10, 4))):
+        x = torch.randn(1, 2, *size, generator=g)
+        stride = [r // 2 for r in roi]
+        adjusted, slc = [0, 0, 0], [None, None, None]
+        for i in range(3):
+            adjusted[i] = (size[i] - roi[i]) // stride[i] * stride[i] + roi[i]
+            start = (size[i] - adjusted[i]) // 2
+            slc[i] = slice(start, start + adjusted[i])
+        ax = x[:, :, slc[0], slc[1], slc[2]]
+        want = ax.unfold(2, roi[0], stride[0]).unfold(3, roi[1], stride[1]).unfold(4, roi[2], stride[2]) \
+                 .flatten(2, 4).permute(2, 1, 0, 3, 4, 5).squeeze(2).contiguous()
+        got = I.sliding_windows(x, roi)
+        assert torch.equal(got, want)
+        _, _, count = I.window_grid(size, roi)
+        assert got.shape[0] == count[0] * count[1] * count[2]
+    assert I.summarize([0.5, 0.7]) == (0.6, 0.09999999999999998)
