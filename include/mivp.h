@@ -141,6 +141,13 @@ int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t*
 int mivp_win_attn_delta(const MivpSwinDesc* d, const void* o, const void* d_o, float* delta,
                         mivp_stream_t stream);
 
+/* EXPERIMENTAL E4M3 variant of mivp_win_attn_fwd for head_dim < 16 without dropout (BASELINE.json configs[4]): same
+ * operands and outputs; Q', K', V and P are converted to fp8 inside the kernel (csrc/swin_fwd_fp8.hip).  Measured against the
+ * bf16 kernel in profiles/r02_fp8_attention.json; not used by the model unless mivp_amd.swin_ops.USE_FP8_ATTN_FWD is set. */
+int mivp_win_attn_fwd_fp8(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
+                          const void* kp, const void* vp, const void* qa, const void* ka,
+                          const int32_t* tok_rid, void* o, float* lse, mivp_stream_t stream);
+
 /* query-owner pass: dq [B*P][heads][Nqp][hd] bf16 (w.r.t. the stored, pre-scaled q).
  * Also WRITES delta [B*P][heads][Nqp] (= mivp_win_attn_delta) for the key-owner pass that follows. */
 int mivp_win_attn_bwd_dq(const MivpSwinDesc* d, const void* q, const void* k, const void* v,

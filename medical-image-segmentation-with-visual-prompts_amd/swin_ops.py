@@ -15,6 +15,8 @@ from .geometry import BlockTables, block_tables, round_up
 
 BF16 = torch.bfloat16
 USE_FUSED_ATTN_BWD = True      # one-pass attention backward where it applies (tests flip it to compare with the two-pass form)
+USE_FP8_ATTN_FWD = False       # EXPERIMENT (BASELINE configs[4]): E4M3 Q'/K'/V/P in the forward attention of head_dim < 16 blocks;
+#                                measured slower-or-equal and 20x less accurate than bf16 (profiles/r02_fp8_attention.json): off
 
 
 @dataclass
@@ -159,8 +161,9 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
             w.aug_cache[aug_key] = (qa, ka)
     o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
     lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
-    L.call("mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp), L.ptr(qa), L.ptr(ka),
-           L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
+    fp8 = USE_FP8_ATTN_FWD and hd < 16 and hd + d.augp <= 32 and not dropout
+    L.call("mivp_win_attn_fwd_fp8" if fp8 else "mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp),
+           L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
     t1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if save else None
     y = torch.empty_like(x)
     L.call("mivp_swin_proj_mlp_fwd", C.byref(d), L.ptr(o), L.ptr(x), L.ptr(tb.tok_src), L.ptr(tb.tok_dst), L.ptr(w.wproj),

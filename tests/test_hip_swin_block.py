@@ -171,3 +171,39 @@ def test_block_sharp_softmax(gain, shift, n_prompt):
     if n_prompt:
         e_dp = rel_l2(dp.float().cpu(), prm.grad)
         assert e_dp < max(4e-2, 3 * yard_dp), (e_dp, yard_dp)
+
+
+@pytest.mark.parametrize("shift,n_prompt", [((0, 0, 0), 64), ((3, 3, 3), 64), ((3, 3, 3), 0)])
+def test_fp8_attention_variant(shift, n_prompt):
+    """The experimental E4M3 forward attention (BASELINE.json configs[4]; csrc/swin_fwd_fp8.hip, off by default -- it is not
+    faster, profiles/r02_fp8_attention.json): same semantics as the bf16 kernel, block output within 1e-2 of the fp32 oracle
+    (3-bit mantissas on Q', K', V, P; the bf16 kernel meets 6e-3) and the saved log-sum-exp within 0.1 of the bf16 kernel's."""
+    import mivp_amd
+    from mivp_amd import swin_ops
+    from oracle import swin_ref as S
+    from oracle.unetr_ref import _block_state
+    window, dims, C, heads = (7, 7, 7), (14, 14, 14), 48, 4
+    gen = torch.Generator().manual_seed(11)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, max(n_prompt, 1), n_prompt > 0, gen)
+    sd = _rounded_state(sd)
+    x = _bf16_round(torch.randn(2, C, *dims, generator=gen))
+    prm = 0.5 * torch.randn(n_prompt, C, generator=gen) if n_prompt else None
+    want = S.swin_block(x, prm, sd, "", window, shift, heads)
+    dev = torch.device("cuda")
+    w = swin_ops.weights_from_state(sd, "", heads, 64, n_prompt, dev)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
+    pd = None if prm is None else prm.to(dev)
+    _, ref = swin_ops.swin_block_forward(xc, pd, w, None, window, shift, save=True)
+    swin_ops.USE_FP8_ATTN_FWD = True
+    try:
+        y, sv = swin_ops.swin_block_forward(xc, pd, w, None, window, shift, save=True)
+    finally:
+        swin_ops.USE_FP8_ATTN_FWD = False
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 1e-2
+    nq = sv.desc.Nq
+    assert float((sv.lse[..., :nq] - ref.lse[..., :nq]).abs().max()) < 0.1
+    assert rel_l2(sv.o.float().cpu(), ref.o.float().cpu()) < 8e-2          # the attention output itself: E4M3 noise
