@@ -510,6 +510,15 @@ int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2:
 int mivp_seg_counts(const float* logits, const float* target, int64_t nvox, int32_t C, int32_t channels_last, int64_t vol,
                     void* counts, mivp_stream_t stream);
 
+/* Transposed convolution with kernel == stride in {1, 2} per axis, no bias (the up-sampling step of MONAI's UnetrUpBlock,
+ * swin_unetr.py:338-348,372-380): x bf16 [B][h][w][d][Cin] -> y bf16 [B][h*s0][w*s1][d*s2][Cout].
+ * w1 bf16 [taps*Cout][Cin] (row (tap, co), tap = (a*s1 + b)*s2 + c of the nn.ConvTranspose3d weight [Cin][Cout][a][b][c]);
+ * the data gradient takes w2 bf16 [Cin][taps*Cout].  Cin % 8 == 0, Cout % 8 == 0.  (Weight gradient: mivp_gemm_tn.) */
+int mivp_convt_fwd(int32_t B, const int32_t* dims, const int32_t* stride, int32_t Cin, int32_t Cout, const void* x, const void* w1,
+                   void* y, mivp_stream_t stream);
+int mivp_convt_dgrad(int32_t B, const int32_t* dims, const int32_t* stride, int32_t Cin, int32_t Cout, const void* dy,
+                     const void* w2, void* dx, mivp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

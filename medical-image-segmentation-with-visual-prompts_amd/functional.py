@@ -559,10 +559,11 @@ def _conv1x1_weights(cache: WeightCache, key, conv):
     return cache.get(key, [conv.weight], build)
 
 
-def unetr_basic_block(owner, key, block, x):
+def unetr_basic_block(owner, key, block, x, layer=None):
     """MONAI ``UnetrBasicBlock`` (stride 1, norm 'instance', LeakyReLU 0.01) on channels-last bf16:
-    conv 3^3 -> IN -> LReLU -> conv 3^3 -> IN [-> + (IN(conv 1^3(x)) | x)] -> LReLU."""
-    lay = block.layer
+    conv 3^3 -> IN -> LReLU -> conv 3^3 -> IN [-> + (IN(conv 1^3(x)) | x)] -> LReLU.  ``layer``: the UnetResBlock /
+    UnetBasicBlock module when it is not ``block.layer`` (UnetrUpBlock calls it ``conv_block``)."""
+    lay = layer if layer is not None else block.layer
     cout = lay.conv1.conv.out_channels
     out = conv3d_plain(owner, f"{key}.c1", lay.conv1.conv, x)
     out = _InstanceNormActFn.apply(out, float(lay.norm1.eps), True)
@@ -578,6 +579,42 @@ def unetr_basic_block(owner, key, block, x):
     else:
         res = x[..., :cout]
     return torch.nn.functional.leaky_relu(out + res, 0.01)
+
+
+class _ConvTransposeFn(torch.autograd.Function):
+    """nn.ConvTranspose3d with kernel == stride, no bias, on channels-last bf16 (csrc/convt.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w1, w2, stride):
+        ctx.save_for_backward(x)
+        ctx.w2 = w2
+        ctx.stride = stride
+        ctx.cin = x.shape[-1]
+        return ops.convt_forward(x, w1, stride, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.convt_dgrad(dy, ctx.w2, ctx.stride, ctx.cin) if ctx.needs_input_grad[0] else None
+        dw = ops.convt_wgrad(x, dy, ctx.stride) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
+
+
+def conv_transpose(owner, key, conv: torch.nn.ConvTranspose3d, x):
+    stride = tuple(int(s) for s in conv.stride)
+    if tuple(conv.kernel_size) != stride or conv.bias is not None:
+        raise NotImplementedError("mivp_amd: ConvTranspose3d with kernel == stride and no bias only (MONAI UnetrUpBlock's form)")
+    w1, w2 = owner._wcache.get(key, [conv.weight], lambda: ops.pack_convt_weight(conv.weight))
+    return _ConvTransposeFn.apply(x, conv.weight, w1, w2, stride)
+
+
+def unetr_up_block(owner, key, block, x, skip):
+    """MONAI ``UnetrUpBlock.forward(inp, skip)``: transposed conv (kernel = stride) -> cat([out, skip]) -> UnetResBlock /
+    UnetBasicBlock (networks/blocks/unetr_block.py), on channels-last bf16."""
+    up = conv_transpose(owner, f"{key}.t", block.transp_conv.conv, x)
+    cat = torch.cat([up, skip], dim=-1)
+    return unetr_basic_block(owner, f"{key}.c", block, cat, layer=block.conv_block)
 
 
 class _PointwiseConvFn(torch.autograd.Function):

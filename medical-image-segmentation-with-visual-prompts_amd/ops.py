@@ -659,3 +659,44 @@ def global_avg_pool(x):
     B, Cc = x.shape[0], x.shape[-1]
     n = x.numel() // (B * Cc)
     return torch.stack([_colsum_bf16(x[b].reshape(n, Cc)) for b in range(B)]) / float(n)
+
+
+# ---------------------------------------------------------------------------------------------
+# transposed convolution, kernel == stride (MONAI UnetrUpBlock's up-sampling step; csrc/convt.hip)
+# ---------------------------------------------------------------------------------------------
+def pack_convt_weight(w: torch.Tensor):
+    """nn.ConvTranspose3d weight [Cin, Cout, s0, s1, s2] -> (w1 bf16 [taps*Cout][Cin] for the forward GEMM,
+    w2 bf16 [Cin][taps*Cout] for the data gradient); column / row (tap, co) with tap = (a*s1 + b)*s2 + c."""
+    cin, cout = w.shape[0], w.shape[1]
+    wf = w.detach().float()
+    w1 = wf.permute(2, 3, 4, 1, 0).reshape(-1, cin).to(BF16).contiguous()
+    w2 = wf.permute(0, 2, 3, 4, 1).reshape(cin, -1).to(BF16).contiguous()
+    return w1, w2
+
+
+def convt_forward(x: torch.Tensor, w1: torch.Tensor, stride, cout: int) -> torch.Tensor:
+    B, h, w, d, cin = x.shape
+    y = torch.empty((B, h * stride[0], w * stride[1], d * stride[2], cout), dtype=BF16, device=x.device)
+    L.call("mivp_convt_fwd", C.c_int32(B), (C.c_int32 * 3)(h, w, d), (C.c_int32 * 3)(*stride), C.c_int32(cin), C.c_int32(cout),
+           L.ptr(x), L.ptr(w1), L.ptr(y), L.stream())
+    return y
+
+
+def convt_dgrad(dy: torch.Tensor, w2: torch.Tensor, stride, cin: int) -> torch.Tensor:
+    B, H, W, D, cout = dy.shape
+    h, w, d = H // stride[0], W // stride[1], D // stride[2]
+    dx = torch.empty((B, h, w, d, cin), dtype=BF16, device=dy.device)
+    L.call("mivp_convt_dgrad", C.c_int32(B), (C.c_int32 * 3)(h, w, d), (C.c_int32 * 3)(*stride), C.c_int32(cin), C.c_int32(cout),
+           L.ptr(dy), L.ptr(w2), L.ptr(dx), L.stream())
+    return dx
+
+
+def convt_wgrad(x: torch.Tensor, dy: torch.Tensor, stride) -> torch.Tensor:
+    """dW [Cin, Cout, s0, s1, s2] f32 = TN GEMM over the low-resolution tokens of x and the space-to-depth view of dy."""
+    B, h, w, d, cin = x.shape
+    cout = dy.shape[-1]
+    s0, s1, s2 = stride
+    dyg = dy.view(B, h, s0, w, s1, d, s2, cout).permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous().view(-1, s0 * s1 * s2 * cout)
+    T = B * h * w * d
+    g = gemm_tn(x.reshape(T, cin), operand_rows(cin), dyg, operand_rows(dyg.shape[1]), T, cin, dyg.shape[1])
+    return g.view(cin, s0, s1, s2, cout).permute(0, 4, 1, 2, 3).contiguous()

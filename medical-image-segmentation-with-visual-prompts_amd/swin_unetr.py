@@ -236,6 +236,43 @@ class UnetrBasicBlock(nn.Module):
         self.layer = _UnetBlockLayer(in_channels, out_channels, self.res_block)
 
 
+class _TransposedConv(nn.Sequential):
+    """State-dict twin of MONAI ``get_conv_layer(..., conv_only=True, is_transposed=True)``: child ``conv``, no bias."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.add_module("conv", nn.ConvTranspose3d(cin, cout, kernel_size=stride, stride=stride, bias=False))
+
+
+class UnetrUpBlock(nn.Module):
+    """Stand-in for MONAI ``UnetrUpBlock(spatial_dims=3, in, out, kernel_size=3, upsample_kernel_size, norm_name='instance',
+    res_block)`` (swin_unetr.py:338-348,372-380 with ``unetr_up_block != 'swin'``): ``transp_conv`` (kernel = stride, no
+    bias) -> cat with the skip -> ``conv_block`` (UnetResBlock | UnetBasicBlock on 2 x out channels).  MONAI is not
+    importable here: structure and state-dict names restated from its documented source, parity unpinned.  The reference
+    cannot run this option (it calls the block with three arguments and up-samples D where the encoder never merged it,
+    SURVEY 8 a16); here the up-sampling stride follows the encoder's merges so that the shapes close, and prompts -- which a
+    convolutional block cannot take -- are ignored."""
+
+    def __init__(self, in_channels, out_channels, upsample_stride, res_block):
+        super().__init__()
+        self.res_block = bool(res_block)
+        self.transp_conv = _TransposedConv(in_channels, out_channels, tuple(int(s) for s in upsample_stride))
+        self.conv_block = _UnetBlockLayer(2 * out_channels, out_channels, self.res_block)
+        self._wcache = Fn.WeightCache()
+
+    def forward(self, x, skip, p=None):
+        return Fn.unetr_up_block(self, "up", self, x, skip)
+
+    def named_parameters_body(self):
+        return list(self.named_parameters())
+
+    def named_parameters_bias_content(self):
+        return []
+
+    def named_parameters_bias_prompt_tokens(self):
+        return []
+
+
 class SwinUpBlock(nn.Module):
     """Decoder stage (swin_unetr/unet_blocks.py:11-92): upsample, crop+concat, BN, LeakyReLU, conv 3^3,
     two Swin blocks."""
@@ -343,10 +380,7 @@ class SwinUnetR(nn.Module):
         c = self.conf
         hc = list(c.hidden_channels)
         depth = c.depth_unet
-        if c.unetr_up_block != "swin":
-            raise NotImplementedError(
-                "mivp_amd: the MONAI UnetrUpBlock option is not built (that path is not runnable in the reference "
-                "either: it is called with three arguments and takes two, SURVEY 8 a16); use unetr_up_block='swin'")
+        swin_up = c.unetr_up_block == "swin"
         self._build_encoder()
         dec_in = [hc[i + 1] for i in range(depth)][::-1]       # channels entering each decoder stage
         dec_out = [hc[i] for i in range(depth)][::-1]
@@ -366,14 +400,21 @@ class SwinUnetR(nn.Module):
                 + [nn.Conv3d(c.input_channels, dec_out[-1], 3, 1, padding=1)])
         else:
             self.residual_blocks = nn.ModuleList([nn.Identity() for _ in range(depth + 1)])
-        self.decoder_blocks = nn.ModuleList([
-            SwinUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), (3, 3, 3), c.pos_bias_embed_dim,
-                        c.num_heads_decoder, c.attn_window_size, c.max_prompts, c.tokens_per_prompt_decoder,
-                        use_token_params=c.use_decoder_prompting, attn_drop=c.attn_drop, proj_drop=c.proj_drop,
-                        use_checkpoint=c.use_checkpoint)
-            for i in range(depth)])
+        if swin_up:
+            self.decoder_blocks = nn.ModuleList([
+                SwinUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), (3, 3, 3), c.pos_bias_embed_dim,
+                            c.num_heads_decoder, c.attn_window_size, c.max_prompts, c.tokens_per_prompt_decoder,
+                            use_token_params=c.use_decoder_prompting, attn_drop=c.attn_drop, proj_drop=c.proj_drop,
+                            use_checkpoint=c.use_checkpoint)
+                for i in range(depth)])
+        else:
+            # CNN decoder (swin_unetr.py:338-348): MONAI UnetrUpBlock; conf.res_block is read unguarded like the reference
+            self.decoder_blocks = nn.ModuleList([
+                UnetrUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), c.res_block) for i in range(depth)])
         if c.unetr_res_block == "none":
             self.output_layer = nn.Upsample(scale_factor=(2, 2, 2), mode="trilinear", align_corners=False)
+        elif not swin_up:
+            self.output_layer = UnetrUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), c.res_block)
         else:
             self.output_layer = SwinUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), (3, 3, 3), c.pos_bias_embed_dim,
                                             c.num_heads_decoder, c.attn_window_size, c.max_prompts,
@@ -406,6 +447,8 @@ class SwinUnetR(nn.Module):
         if side == "enc" and not self.conf.use_encoder_prompting:
             return (None, None)
         if side in ("dec", "out") and not self.conf.use_decoder_prompting:
+            return (None, None)
+        if side == "out" and side not in self.prompt_tokens:      # CNN up blocks take no prompts (no 'out' tokens are built)
             return (None, None)
         lst = self.prompt_tokens[side]
         return (lst[2 * j], lst[2 * j + 1])

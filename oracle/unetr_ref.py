@@ -110,17 +110,33 @@ def _basic_block_state(sd, prefix, cin, cout, res_block, gen):
         sd[f"{prefix}layer.conv3.conv.weight"] = _uniform((cout, cin, 1, 1, 1), 1 / math.sqrt(cin), gen)
 
 
-def basic_block_forward(x: Tensor, sd, prefix: str, res_block: bool) -> Tensor:
+def basic_block_forward(x: Tensor, sd, prefix: str, res_block: bool, inner: str = "layer.") -> Tensor:
     """MONAI ``UnetResBlock.forward`` / ``UnetBasicBlock.forward`` with norm 'instance' and LeakyReLU(0.01), stride 1."""
-    out = F.conv3d(x, sd[f"{prefix}layer.conv1.conv.weight"], None, padding=1)
+    out = F.conv3d(x, sd[f"{prefix}{inner}conv1.conv.weight"], None, padding=1)
     out = F.leaky_relu(F.instance_norm(out, eps=1e-5), 0.01)
-    out = F.instance_norm(F.conv3d(out, sd[f"{prefix}layer.conv2.conv.weight"], None, padding=1), eps=1e-5)
+    out = F.instance_norm(F.conv3d(out, sd[f"{prefix}{inner}conv2.conv.weight"], None, padding=1), eps=1e-5)
     if res_block:
         residual = x
-        if f"{prefix}layer.conv3.conv.weight" in sd:
-            residual = F.instance_norm(F.conv3d(x, sd[f"{prefix}layer.conv3.conv.weight"], None), eps=1e-5)
+        if f"{prefix}{inner}conv3.conv.weight" in sd:
+            residual = F.instance_norm(F.conv3d(x, sd[f"{prefix}{inner}conv3.conv.weight"], None), eps=1e-5)
         out = out + residual
     return F.leaky_relu(out, 0.01)
+
+
+def unetr_up_block_forward(x: Tensor, skip: Tensor, sd, prefix: str, stride, res_block: bool) -> Tensor:
+    """MONAI ``UnetrUpBlock.forward`` (networks/blocks/unetr_block.py): ConvTranspose3d(kernel = stride, no bias) -> cat with
+    the skip -> UnetResBlock | UnetBasicBlock.  Restated from MONAI's documented source: parity unpinned."""
+    up = F.conv_transpose3d(x, sd[f"{prefix}transp_conv.conv.weight"], None, stride=tuple(stride))
+    return basic_block_forward(torch.cat([up, skip], dim=1), sd, prefix, res_block, inner="conv_block.")
+
+
+def _up_block_state(sd, prefix, cin, cout, stride, res_block, gen):
+    k = stride[0] * stride[1] * stride[2]
+    sd[f"{prefix}transp_conv.conv.weight"] = _uniform((cin, cout) + tuple(stride), 1 / math.sqrt(cout * k), gen)
+    for name, ci in (("conv1", 2 * cout), ("conv2", cout)):
+        sd[f"{prefix}conv_block.{name}.conv.weight"] = _uniform((cout, ci, 3, 3, 3), 1 / math.sqrt(ci * 27), gen)
+    if res_block:
+        sd[f"{prefix}conv_block.conv3.conv.weight"] = _uniform((cout, 2 * cout, 1, 1, 1), 1 / math.sqrt(2 * cout), gen)
 
 
 def random_state(conf: Namespace, seed: int = 0) -> "OrderedDict[str, Tensor]":
@@ -180,13 +196,18 @@ def random_state(conf: Namespace, seed: int = 0) -> "OrderedDict[str, Tensor]":
             _conv_state(sd, f"residual_blocks.{depth}.", conf.input_channels, in_chs[-1], 3, gen)
         for j in range(depth):
             cin, cout = out_chs[j], in_chs[j]
+            if conf.unetr_up_block != "swin":
+                _up_block_state(sd, f"decoder_blocks.{j}.", cin, cout, (2, 2, 1 if j < depth - 1 else 2), conf.res_block, gen)
+                continue
             hid = cin + cin // 2
             _bn_state(sd, f"decoder_blocks.{j}.norm_concat.", hid)
             _conv_state(sd, f"decoder_blocks.{j}.conv_concat.conv.", hid, cout, 3, gen)
             for b in range(2):
                 _block_state(sd, f"decoder_blocks.{j}.swin_layer.swin_blocks.{b}.", cout, conf.num_heads_decoder,
                              win, E, conf.tokens_per_prompt_decoder, conf.use_decoder_prompting, gen)
-        if conf.unetr_res_block != "none":
+        if conf.unetr_res_block != "none" and conf.unetr_up_block != "swin":
+            _up_block_state(sd, "output_layer.", in_chs[-1], in_chs[-1], (2, 2, 2), conf.res_block, gen)
+        elif conf.unetr_res_block != "none":
             c = in_chs[-1]
             _bn_state(sd, "output_layer.norm_concat.", 2 * c)
             _conv_state(sd, "output_layer.conv_concat.conv.", 2 * c, c, 3, gen)
@@ -214,9 +235,6 @@ class OracleSwinUnetR:
         self.emulate_bf16 = emulate_bf16
         if conf.training_mode not in TRAINING_MODES:
             raise ValueError(f"Training mode {conf.training_mode} not available!")
-        if conf.unetr_up_block != "swin":
-            raise NotImplementedError(
-                "the MONAI UnetrUpBlock path has no oracle (MONAI absent; not runnable in the reference, SURVEY a16)")
         self.conf = conf
         self.sd = sd if sd is not None else random_state(conf, seed)
 
@@ -265,6 +283,9 @@ class OracleSwinUnetR:
             elif conf.unetr_res_block == "full":
                 skip = basic_block_forward(skip, sd, f"residual_blocks.{j}.", conf.basic_block_res)
             strides = (2, 2, 1 if j < depth - 1 else 2)
+            if conf.unetr_up_block != "swin":
+                dec = unetr_up_block_forward(dec, skip, sd, f"decoder_blocks.{j}.", strides, conf.res_block)
+                continue
             dec = S.up_block(dec, skip, pr, sd, f"decoder_blocks.{j}.", strides, conf.attn_window_size,
                              conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb, self.emulate_bf16)
         if conf.unetr_res_block == "none":
@@ -277,6 +298,8 @@ class OracleSwinUnetR:
             skip = basic_block_forward(feats[-1], sd, f"residual_blocks.{depth}.", conf.basic_block_res)
         else:
             skip = F.conv3d(feats[-1], sd[f"residual_blocks.{depth}.weight"], sd[f"residual_blocks.{depth}.bias"], padding=1)
+        if conf.unetr_up_block != "swin":
+            return unetr_up_block_forward(dec, skip, sd, "output_layer.", (2, 2, 2), conf.res_block)
         return S.up_block(dec, skip, pr, sd, "output_layer.", (2, 2, 2), conf.attn_window_size,
                           conf.num_heads_decoder, conf.pos_bias_embed_dim, training, nb, self.emulate_bf16)
 

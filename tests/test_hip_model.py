@@ -442,3 +442,31 @@ def test_unetr_res_block_full(res_block, mode, ep, dp):
     trainable = OracleSwinUnetR(conf, sd).trainable_keys()
     # instance norms over 32-256 voxels at the deep stages: same conditioning regime as the 16^3 BatchNorm fixtures
     _check_all_gradients(conf, sd, x, gouts, trainable, 2.5e-2)
+
+
+@pytest.mark.parametrize("res_block,unetr_res", [(True, "none"), (False, "simple")])
+def test_unetr_up_block_option(res_block, unetr_res):
+    """``unetr_up_block != 'swin'``: the CNN decoder of MONAI ``UnetrUpBlock`` s -- ConvTranspose3d k = s ->
+    cat -> UnetResBlock / UnetBasicBlock.  The reference cannot run this option, so the oracle is the
+    restatement of MONAI's documented block (parity unpinned); forward and every parameter gradient, and MONAI's state-dict
+    names."""
+    import mivp_amd
+    from mivp_amd import train
+    from oracle.unetr_ref import OracleSwinUnetR, random_state
+    conf, _, _ = train.make_conf("tiny")
+    conf.training_mode = "supervised_learning_decoder"
+    conf.use_encoder_prompting = conf.use_decoder_prompting = False
+    conf.unetr_up_block = "unetr"
+    conf.unetr_res_block = unetr_res
+    conf.res_block = res_block
+    size, batch = 32, 2
+    sd = round_weights(random_state(conf, seed=23))
+    assert "decoder_blocks.0.transp_conv.conv.weight" in sd and "decoder_blocks.2.conv_block.conv2.conv.weight" in sd
+    assert ("decoder_blocks.1.conv_block.conv3.conv.weight" in sd) == res_block
+    assert ("output_layer.transp_conv.conv.weight" in sd) == (unetr_res != "none")
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(batch, conf.input_channels, size, size, size, generator=g)
+    gouts = {"latent_outputs": torch.randn(batch, conf.hidden_channels[0], size, size, size, generator=g) / size ** 1.5,
+             "seg_pred": torch.randn(batch, conf.output_channels_pretrain, size, size, size, generator=g) / size ** 1.5}
+    trainable = OracleSwinUnetR(conf, sd).trainable_keys()
+    _check_all_gradients(conf, sd, x, gouts, trainable, 2.5e-2)

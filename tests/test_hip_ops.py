@@ -468,3 +468,35 @@ def test_upsample_align_corners(scale, dims):
     torch.cuda.synchronize()
     assert rel_l2(cf(y), want.detach()) < 4e-3
     assert rel_l2(cf(dx), x.grad) < 4e-3
+
+
+@pytest.mark.parametrize("stride,cin,cout,dims", [((2, 2, 2), 96, 48, (6, 5, 7)), ((2, 2, 1), 384, 192, (3, 3, 6)), ((2, 2, 2), 16, 8, (4, 4, 4))])
+def test_conv_transpose_k2s2(stride, cin, cout, dims):
+    """ConvTranspose3d with kernel == stride, no bias (MONAI UnetrUpBlock's up-sampling step, swin_unetr.py:338-348): forward,
+    data gradient and weight gradient against torch's own nn.functional.conv_transpose3d in fp32 on the bf16-rounded operands
+    (a stock layer: torch is the oracle; parity unpinned at the MONAI boundary)."""
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.ConvTranspose3d(cin, cout, kernel_size=stride, stride=stride, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(r16(conv.weight))
+    x = r16(torch.randn(2, cin, *dims, generator=g))
+    xr = x.clone().requires_grad_(True)
+    want = torch.nn.functional.conv_transpose3d(xr, conv.weight, None, stride=stride)
+    gout = r16(torch.randn(want.shape, generator=g))
+    want.backward(gout)
+    dw_want = conv.weight.grad.clone()
+    conv.weight.grad = None
+    conv = conv.to(DEV)
+
+    class Owner:
+        _wcache = Fn.WeightCache()
+
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16).requires_grad_(True)
+    y = Fn.conv_transpose(Owner, "t", conv, xc)
+    y.backward(gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16))
+    torch.cuda.synchronize()
+    assert rel_l2(y.detach().float().cpu().permute(0, 4, 1, 2, 3), want.detach()) < 3e-3       # bf16 output rounding
+    assert rel_l2(xc.grad.float().cpu().permute(0, 4, 1, 2, 3), xr.grad) < 3e-3
+    assert rel_l2(conv.weight.grad.cpu(), dw_want) < 2e-3
