@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3d_fwd(MivpConvDesc d, const bf
     int* tapoff = reinterpret_cast<int*>(smem + 2 * (XBYTES + WBYTES));    // [28] element offset of each tap (27 = none)
     float* aff = reinterpret_cast<float*>(tapoff + 32);                   // [2][Cin] when pro_affine
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
     const long vol = (long)H * W * D;
@@ -465,7 +465,7 @@ constexpr int WR_AS = 6, WR_BS = 4, WR_MT = 5;
 __global__ __launch_bounds__(256) void k_conv3d_wgrad_rows(MivpConvDesc d, const bf16_t* __restrict__ x,
                                                            const bf16_t* __restrict__ dy, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
     const int Dp = (D + 31) / 32 * 32, G8 = Cin / 8;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
     // zero padding comes after the activation).  scale | shift live behind the tile buffers: [2][Cin] f32.
     float* aff = reinterpret_cast<float*>(smem + 2 * (HALO_BYTES + WBYTES));
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int H = d.dims[0], W = d.dims[1], D = d.dims[2], Cin = d.Cin;
     // blockIdx.y = group of BN output channels (convolutions with many output channels re-stage the halo per group:

@@ -51,7 +51,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const bf16_t* __restrict__ x,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          const bf16_t* __restrict__ w, bf16_t* __restrict__ y) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
     const int kC = (d.merge_last ? 8 : 4) * C;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
                                                          bf16_t* __restrict__ wg_dn, bf16_t* __restrict__ wg_x) {
     // wg_dn / wg_x (optional, weight-gradient mode): [T][kC] gradient w.r.t. the LayerNorm output and the gathered
     // (front-padded) LayerNorm input rows, the operands of mivp_ln_wgrad / mivp_gemm_tn
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, Cout = d.Cout;
     const int kC = (d.merge_last ? 8 : 4) * C;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
     // dn_out / dyw (optional, weight-gradient mode): gradient w.r.t. the mlp_norm output and dy in window order;
     // d_pj (optional): dt1 under the proj-dropout mask = gradient w.r.t. the proj output
     constexpr int KS = (CT + 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
     const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
     char* Kt = Vimg + (size_t)ckeys * VROWB;
     int* ridk = reinterpret_cast<int*>(Kt + (size_t)(16 * DVT) * KTROW);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
     const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4, dvp4 = DVP / 4;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
     float* del_s = lse_s + cq;
     int* ridq = reinterpret_cast<int*>(del_s + cq);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
     const int hd4 = hd / 4, dk4 = DK / 4, a4 = A / 4, dvp4 = DVP / 4;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
                                                       bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out) {
     // dn_out (optional, weight-gradient mode): gradient w.r.t. the attn_norm output, window order
     constexpr int KS3 = (3 * 16 * CT + 31) / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, hd = C / d.heads, n3 = 3 * C;
     const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);

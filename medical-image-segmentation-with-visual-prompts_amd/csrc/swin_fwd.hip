@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
                                                       const bf16_t* __restrict__ wqkv,
                                                       bf16_t* __restrict__ q, bf16_t* __restrict__ k,
                                                       bf16_t* __restrict__ v) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, hd = C / d.heads;
     const long T = (long)d.B * d.P * d.Nqp;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     constexpr int PCS = (64 * KS + 255) / 256;                      // 16-byte pieces of a slab per thread
     __shared__ __attribute__((aligned(16))) char wsm[LDSW ? 2 * KS * 1024 : 16];
     using WR = OperandRows<32>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
     const long T = (long)d.B * d.P * d.Nqp;
