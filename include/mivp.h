@@ -167,6 +167,14 @@ int mivp_win_attn_bwd_fused(const MivpSwinDesc* d, const void* q, const void* k,
                             void* dq, void* dk, void* dv, float* dkp_part, float* dvp_part, float* dtok_part,
                             mivp_stream_t stream);
 
+/* Prompt-only attention backward for the first prompted block behind a frozen stem (no data gradient there): the prompt
+ * keys' per-window partials dkp_part / dvp_part / dtok_part exactly as mivp_win_attn_bwd_dkv writes them, from one launch
+ * that also forms delta (head_dim <= 16, Npp / 16 in {1, 2, 4, 8}; mivp_win_attn_bwd_prompt_supported tells). */
+int mivp_win_attn_bwd_prompt_supported(const MivpSwinDesc* d);
+int mivp_win_attn_bwd_prompt(const MivpSwinDesc* d, const void* q, const void* kp, const void* vp, const void* qa,
+                             const void* ka, const void* o, const void* d_o, const float* lse, float* dkp_part,
+                             float* dvp_part, float* dtok_part, mivp_stream_t stream);
+
 /* key-owner pass: dk, dv [B*P][heads][Nqp][hd] bf16 for window keys;
  *   dkp_part, dvp_part [B*P][heads][Npp][hd] f32 and dtok_part [B*P][heads][Npp] f32:
  *   per-window partial sums for the prompt keys (reduced by mivp_reduce_rows)            */

@@ -101,6 +101,39 @@ MIVP_DEV uint32_t attn_row(long bph, int q, int Nqp, int Nkp) {
 }
 MIVP_DEV uint32_t attn_pair(uint32_t row, int k) { return row + (uint32_t)(k >> 1); }
 
+// ---------------------------------------------------------------------------------------------
+// Branch-free loads.  The token kernels run few waves per CU at the deep stages, so their run time is the NUMBER OF
+// DEPENDENT global-load round trips (~1 us each), not bytes or flops.  A load under `if (in range)` compiles to its own
+// basic block with an s_waitcnt vmcnt(0) right behind it -- one round trip per load (tools/isa_waits.py counts them).
+// The idiom used instead: clamp the address into the allocation, load unconditionally, AND the value with a mask.
+//   sel()     : the arms are by-value parameters, so clang emits a select (v_cndmask), never control flow
+//   keep_if() : value or zero as a bitwise AND (a `cond ? v : 0` select is turned back into a branch around the load)
+//   FastDiv   : n / d for n, d < 2^16 as one v_mul_hi (the per-piece `/ C`, `/ head_dim` were ~35 VALU instructions each)
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+MIVP_DEV int sel(bool c, int a, int b) { return c ? a : b; }
+MIVP_DEV long sel(bool c, long a, long b) { return c ? a : b; }
+MIVP_DEV float sel(bool c, float a, float b) { return c ? a : b; }
+MIVP_DEV bf16x4 keep_if(bf16x4 v, bool ok) {
+    u32x2 u = __builtin_bit_cast(u32x2, v);
+    const unsigned m = 0u - (unsigned)ok;
+    u[0] &= m; u[1] &= m;
+    return __builtin_bit_cast(bf16x4, u);
+}
+MIVP_DEV bf16x8 keep_if(bf16x8 v, bool ok) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+    const unsigned m = 0u - (unsigned)ok;
+    u[0] &= m; u[1] &= m; u[2] &= m; u[3] &= m;
+    return __builtin_bit_cast(bf16x8, u);
+}
+struct FastDiv {
+    uint32_t m, d;
+    MIVP_DEV explicit FastDiv(int div) : m(0xFFFFFFFFu / (uint32_t)div + 1u), d((uint32_t)div) {}
+    MIVP_DEV int div(int n) const { return (int)__umulhi((uint32_t)n, m); }          // exact for 0 <= n < 2^16, d < 2^16
+    MIVP_DEV int mod(int n) const { return n - div(n) * (int)d; }
+};
+
 // LDS image of 16-byte-chunked operand rows read as MFMA fragments (lane = (row r, chunk g), ds_read_b128).
 // DK == 32: rows are exactly 64 bytes and the chunk index is XOR-swizzled with {0,3,2,1}[(row >> 2) & 3], which
 // makes every 16-lane service group of ds_read_b128 cover all sixteen 16-byte slots of the 256-byte bank row
@@ -115,13 +148,38 @@ struct OperandRows {
     }
 };
 
-// Workgroup-shared weight slabs for the token GEMM kernels of the wide stages.  Those kernels are bound by weight
-// fetch: each wave used to pull the whole weight matrix through L1 for its 16 tokens.  A slab is 16 consecutive rows x
-// 32*KSL columns of a row-major bf16 matrix, staged by the 256 threads of the workgroup as KSL sub-tiles of
-// [16 rows][64 B] in the swizzled operand layout (OperandRows<32>); two slabs are in flight (global -> registers one
-// slab ahead, the other buffer was last read one iteration earlier, one barrier per slab).
+// Weight fragment images (host: pack_weight_frags / mivp.h): [row tile nt][k-step s][lane][8] bf16 -- the A fragment of
+// (nt, s) is 1 KB contiguous, lane l's 16 bytes at 16 l.
+MIVP_DEV bf16x8 wfrag(const bf16_t* __restrict__ wf, int ks, int nt, int s, int lane) {
+    return ld8(wf + ((long)(nt * ks + s) * 64 + lane) * 8);
+}
+// Workgroup-shared weight slabs for the token GEMM kernels of the wide stages (each wave used to pull the whole matrix
+// through L1 for its 16 tokens).  A slab is one row tile of a fragment image: KSL KB, copied as is by the 256 threads
+// (linear, fully coalesced; the LDS reads are lane-linear too: no bank conflicts); two slabs are in flight (global ->
+// registers one slab ahead, the other buffer was last read one iteration earlier, one barrier per slab).
 template <int KSL>
 struct WeightSlabs {
+    static constexpr int PCS = (64 * KSL + 255) / 256;            // 16-byte pieces per thread
+    static constexpr int BYTES = 2 * KSL * 1024;
+    bf16x8 reg[PCS];
+    MIVP_DEV void fetch(const bf16_t* __restrict__ wf, int nt) {   // (the ragged last piece repeats the final one)
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) reg[u] = ld8(wf + (long)nt * KSL * 512 + 8 * min((int)threadIdx.x + 256 * u, 64 * KSL - 1));
+    }
+    MIVP_DEV void store(char* smem, int buf) const {
+#pragma unroll
+        for (int u = 0; u < PCS; ++u)
+            *reinterpret_cast<bf16x8*>(smem + buf * KSL * 1024 + 16 * min((int)threadIdx.x + 256 * u, 64 * KSL - 1)) = reg[u];
+    }
+    static MIVP_DEV bf16x8 frag(const char* smem, int buf, int s, int lane) {
+        return *reinterpret_cast<const bf16x8*>(smem + buf * KSL * 1024 + s * 1024 + 16 * lane);
+    }
+};
+
+// The same for a ROW-MAJOR matrix (patch merging / expanding weights, merge_up.hip): a slab is 16 consecutive rows x 32*KSL
+// columns staged as KSL sub-tiles of [16 rows][64 B] in the swizzled operand layout (OperandRows<32>).
+template <int KSL>
+struct WeightSlabsRM {
     static constexpr int PCS = (64 * KSL + 255) / 256;            // 16-byte pieces per thread
     static constexpr int BYTES = 2 * KSL * 1024;
     bf16x8 reg[PCS];

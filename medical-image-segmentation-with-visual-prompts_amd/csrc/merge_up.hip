@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const 
     const int per_y = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int nt_lo = blockIdx.y * per_y, nt_hi = (nt_lo + per_y) < n_tiles ? (nt_lo + per_y) : n_tiles;
     // the four waves share each 16-row weight slab through LDS (WeightSlabs, common.hpp): kC is 384 or more here
-    using WS = WeightSlabs<KS>;
+    using WS = WeightSlabsRM<KS>;
     __shared__ __attribute__((aligned(16))) char wsm[WS::BYTES];
     WS ws;
     if (nt_lo < nt_hi) { ws.fetch(w, kC, 16 * nt_lo, d.Cout, kC); ws.store(wsm, 0); __syncthreads(); }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_patch_merge_bwd(MivpMergeDesc d, const 
     const int per_y = (n_ct + gridDim.y - 1) / gridDim.y;
     const int ct_lo = blockIdx.y * per_y, ct_hi = (ct_lo + per_y) < n_ct ? (ct_lo + per_y) : n_ct;
     // weight slabs shared by the four waves through LDS (WeightSlabs, common.hpp)
-    using WS = WeightSlabs<NS>;
+    using WS = WeightSlabsRM<NS>;
     __shared__ __attribute__((aligned(16))) char wsm[WS::BYTES];
     WS ws;
     if (ct_lo < ct_hi) { ws.fetch(w_t, Cout, 16 * ct_lo, kC, Cout); ws.store(wsm, 0); __syncthreads(); }

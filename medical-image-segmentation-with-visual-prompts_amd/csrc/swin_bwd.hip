@@ -9,6 +9,10 @@
 #include "common.hpp"
 
 int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
+// swin_tok_wide.hip: the column-split token kernels of the wide stages
+int mivp_tok_wide_supported(const MivpSwinDesc* d);
+int mivp_tok_wide_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x, const int32_t* tok_src,
+                          const float* ln_w, const void* wqkv_t, const void* d_t1, void* dx, void* dn_out, hipStream_t st);
 
 namespace {
 
@@ -35,8 +39,10 @@ MIVP_DEV TokInfo token_info(const MivpSwinDesc& d, long t) {
 //   dh  = dt2 Wmlp            (A = Wmlp^T rows = input channel)
 //   dt1 = dt2 + LNbwd(dh ; t1) ; dO = dt1 Wproj
 // ---------------------------------------------------------------------------------------------
+// (second launch bound = waves per SIMD the register allocation must leave room for: the C = 192 form sat just above 256
+// VGPRs -- one workgroup per CU, and the 352 workgroups of a 12 x 12 x 24-token stage ran as two rounds)
 template <int CT>
-__global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 3 : 4)) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dy,
                                                            const int* __restrict__ tok_dst, const bf16_t* __restrict__ t1,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                            const bf16_t* __restrict__ wmlp_t, const bf16_t* __restrict__ wproj_t,
@@ -50,46 +56,50 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
     const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);
-    const int dst = ti.live ? tok_dst[ti.pw * d.Nqp + ti.slot] : -1;
-    const bf16_t* dyrow = dy + (ti.b * d.vol_out + (dst >= 0 ? dst : 0)) * (long)C;
+    const int dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
+    const bf16_t* dyrow = dy + (ti.b * d.vol_out + max(dst, 0)) * (long)C;
 
+    // every load of the token tile up front, unconditional (common.hpp "Branch-free loads"): the t1 row first (it does not
+    // wait for tok_dst), then dy as the GEMM's B operand and again in the output lane map (the residual term of dt1)
+    bf16x4 t1raw[CT], dyraw[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) t1raw[ct] = ld4(t1 + ti.tt * (long)C + min(16 * ct + 4 * g, C - 4));
     bf16x8 dyb[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int c = 32 * s + 8 * g;
-        dyb[s] = (dst >= 0 && c < C) ? ld8(dyrow + c) : zero8();
+        dyb[s] = keep_if(ld8(dyrow + min(c, C - 8)), dst >= 0 && c < C);
     }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dyraw[ct] = ld4(dyrow + min(16 * ct + 4 * g, C - 4));
     f32x4 dh[CT], tv[CT];
     float sum = 0.f;
     constexpr bool LDSW = CT >= 6;                              // wide stages share the weights through LDS (common.hpp)
     using WS = WeightSlabs<KS>;
     __shared__ __attribute__((aligned(16))) char wsm[LDSW ? WS::BYTES : 16];
     WS ws;
-    if (LDSW) { ws.fetch(wmlp_t, C, 0, C, C); ws.store(wsm, 0); __syncthreads(); }
+    if (LDSW) { ws.fetch(wmlp_t, 0); ws.store(wsm, 0); __syncthreads(); }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         f32x4 acc = fzero4();
         const int row = 16 * ct + r;
         if (LDSW) {
-            if (ct + 1 < CT) ws.fetch(wmlp_t, C, 16 * (ct + 1), C, C);
+            if (ct + 1 < CT) ws.fetch(wmlp_t, ct + 1);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma16(WS::frag8(wsm, ct & 1, s, r, 8 * g), dyb[s], acc);
+            for (int s = 0; s < KS; ++s) acc = mfma16(WS::frag(wsm, ct & 1, s, lane), dyb[s], acc);
             if (ct + 1 < CT) ws.store(wsm, (ct + 1) & 1);
             __syncthreads();
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int c = 32 * s + 8 * g;
-                bf16x8 a = zero8();
-                if (row < C && c < C) a = ld8(wmlp_t + (long)row * C + c);
-                acc = mfma16(a, dyb[s], acc);
+                acc = mfma16(wfrag(wmlp_t, KS, ct, s, lane), dyb[s], acc);
             }
         }
         dh[ct] = acc;
         const int n0 = 16 * ct + 4 * g;
         if (dn_out && ti.live && n0 < C) st4(dn_out + ti.tt * (long)C + n0, pack4(acc));
-        f32x4 v = fzero4();
-        if (ti.live && n0 < C) { const bf16x4 raw = ld4(t1 + ti.tt * (long)C + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
+        f32x4 v;
+        { const bf16x4 raw = keep_if(t1raw[ct], ti.live && n0 < C); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
         tv[ct] = v;
         sum += v[0] + v[1] + v[2] + v[3];
     }
@@ -125,8 +135,8 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
         if (ct < CT) {
             const int n0 = 16 * ct + 4 * g;
             if (n0 < C) {
-                f32x4 v = fzero4();
-                if (dst >= 0) { const bf16x4 raw = ld4(dyrow + n0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
+                f32x4 v;
+                { const bf16x4 raw = keep_if(dyraw[ct], dst >= 0); for (int j = 0; j < 4; ++j) v[j] = (float)raw[j]; }
                 if (dyw && ti.live) st4(dyw + ti.tt * (long)C + n0, pack4(v));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rstd * (dh[ct][j] - m1 - tv[ct][j] * m2);
@@ -146,29 +156,22 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_bwd(MivpSwinDesc d, const
         }
         g1[ct] = out;
     }
-    if (LDSW) { ws.fetch(wproj_t, C, 0, C, C); ws.store(wsm, 0); __syncthreads(); }    // buffer 0: last read before GEMM A's final barrier
+    if (LDSW) { ws.fetch(wproj_t, 0); ws.store(wsm, 0); __syncthreads(); }    // buffer 0: last read before GEMM A's final barrier
 #pragma unroll
     for (int mt = 0; mt < CT; ++mt) {
         f32x4 acc = fzero4();
         const int row = 16 * mt + r;
         if (LDSW) {
-            if (mt + 1 < CT) ws.fetch(wproj_t, C, 16 * (mt + 1), C, C);
+            if (mt + 1 < CT) ws.fetch(wproj_t, mt + 1);
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                acc = mfma16(cat44(WS::frag4(wsm, mt & 1, s, r, 4 * g), WS::frag4(wsm, mt & 1, s, r, 16 + 4 * g)),
-                             cat44(g1[2 * s], g1[2 * s + 1]), acc);
+            for (int s = 0; s < KS; ++s)                          // (paired image: the fragment is already lo | hi)
+                acc = mfma16(WS::frag(wsm, mt & 1, s, lane), cat44(g1[2 * s], g1[2 * s + 1]), acc);
             if (mt + 1 < CT) ws.store(wsm, (mt + 1) & 1);
             __syncthreads();
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                bf16x4 lo = zero4(), hi = zero4();
-                const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
-                if (row < C) {
-                    if (c0 < C) lo = ld4(wproj_t + (long)row * C + c0);
-                    if (c1 < C) hi = ld4(wproj_t + (long)row * C + c1);
-                }
-                acc = mfma16(cat44(lo, hi), cat44(g1[2 * s], g1[2 * s + 1]), acc);
+                acc = mfma16(wfrag(wproj_t, KS, mt, s, lane), cat44(g1[2 * s], g1[2 * s + 1]), acc);
             }
         }
         const int n0 = 16 * mt + 4 * g;
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
 // QKV + LayerNorm + gather backward:  (dq, dk, dv, dt1) -> dx
 // ---------------------------------------------------------------------------------------------
 template <int CT>
-__global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dq,
+__global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 3 : 4)) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16_t* __restrict__ dq,
                                                       const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
                                                       const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
@@ -764,29 +767,44 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, hd = C / d.heads, n3 = 3 * C;
-    const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);
-    const int src = ti.live ? tok_src[ti.pw * d.Nqp + ti.slot] : -2;
+    const TokInfo ti = token_info(d, ((long)blockIdx.x * 4 + wave) * 16 + r);      // (a dead lane decodes as token 0)
+    const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
 
+    // Every load of the token tile is unconditional and issued up front (common.hpp "Branch-free loads"): the dq | dk |
+    // dv pieces, the dt1 row, then -- one round trip later, behind tok_src -- the x row.
+    const FastDiv by_c(C), by_hd(hd);
+    const long to_dk = dk - dq, to_dv = dv - dq;                  // the three gradients as one base + offset
+    const long row_qkv = (ti.bp * d.heads * d.Nqp + ti.slot) * (long)hd;         // + head * Nqp * hd + j0
+    bf16x4 gpc[KS3][2];
+#pragma unroll
+    for (int s = 0; s < KS3; ++s)
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int n0 = min(32 * s + 8 * g + 4 * hlf, n3 - 4);
+            const int which = by_c.div(n0), cc = n0 - which * C, head = by_hd.div(cc), j0 = cc - head * hd;
+            const long base = sel(which == 0, 0L, sel(which == 1, to_dk, to_dv));
+            gpc[s][hlf] = ld4(dq + base + row_qkv + (long)head * d.Nqp * hd + j0);
+        }
+    bf16x4 t1raw[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) t1raw[ct] = ld4(d_t1 + ti.tt * (long)C + min(16 * ct + 4 * g, C - 4));
+    bf16x4 xraw[CT];
+    const long xrow = (ti.b * d.vol_in + max(src, 0)) * (long)C;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) xraw[ct] = ld4(x + xrow + min(16 * ct + 4 * g, C - 4));
     bf16x8 gb[KS3];
 #pragma unroll
     for (int s = 0; s < KS3; ++s) {
-        bf16x4 piece[2];
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int n0 = 32 * s + 8 * g + 4 * hlf;
-            bf16x4 val = zero4();
-            if (ti.live && n0 < n3) {
-                const int sel = n0 / C, cc = n0 - sel * C, head = cc / hd, j0 = cc - head * hd;
-                const bf16_t* base = sel == 0 ? dq : (sel == 1 ? dk : dv);
-                val = ld4(base + ((ti.bp * d.heads + head) * d.Nqp + ti.slot) * (long)hd + j0);
-                if (sel == 0) {
+            bf16x4 val = keep_if(gpc[s][hlf], ti.live && n0 < n3);
+            const float sc = sel(n0 < C, d.q_scale, 1.0f);        // the q part carries the attention scale (x 1 is exact)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) val[j] = (bf16_t)((float)val[j] * d.q_scale);
-                }
-            }
-            piece[hlf] = val;
+            for (int j = 0; j < 4; ++j) val[j] = (bf16_t)((float)val[j] * sc);
+            gpc[s][hlf] = val;
         }
-        gb[s] = cat44(piece[0], piece[1]);
+        gb[s] = cat44(gpc[s][0], gpc[s][1]);
     }
     f32x4 dyv[CT], xv[CT];
     float sum = 0.f;
@@ -794,31 +812,28 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
     using WS = WeightSlabs<KS3>;
     __shared__ __attribute__((aligned(16))) char wsm[LDSW ? WS::BYTES : 16];
     WS ws;
-    if (LDSW) { ws.fetch(wqkv_t, n3, 0, C, n3); ws.store(wsm, 0); __syncthreads(); }
+    if (LDSW) { ws.fetch(wqkv_t, 0); ws.store(wsm, 0); __syncthreads(); }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         f32x4 acc = fzero4();
         const int row = 16 * ct + r;
         if (LDSW) {
-            if (ct + 1 < CT) ws.fetch(wqkv_t, n3, 16 * (ct + 1), C, n3);
+            if (ct + 1 < CT) ws.fetch(wqkv_t, ct + 1);
 #pragma unroll
-            for (int s = 0; s < KS3; ++s) acc = mfma16(WS::frag8(wsm, ct & 1, s, r, 8 * g), gb[s], acc);
+            for (int s = 0; s < KS3; ++s) acc = mfma16(WS::frag(wsm, ct & 1, s, lane), gb[s], acc);
             if (ct + 1 < CT) ws.store(wsm, (ct + 1) & 1);
             __syncthreads();
         } else {
 #pragma unroll
             for (int s = 0; s < KS3; ++s) {
-                const int n0 = 32 * s + 8 * g;
-                bf16x8 a = zero8();
-                if (row < C && n0 < n3) a = ld8(wqkv_t + (long)row * n3 + n0);
-                acc = mfma16(a, gb[s], acc);
+                acc = mfma16(wfrag(wqkv_t, KS3, ct, s, lane), gb[s], acc);
             }
         }
         dyv[ct] = acc;
         const int c0 = 16 * ct + 4 * g;
         if (dn_out && ti.live && c0 < C) st4(dn_out + ti.tt * (long)C + c0, pack4(acc));
-        f32x4 xx = fzero4();
-        if (src >= 0 && c0 < C) { const bf16x4 raw = ld4(x + ((ti.b * d.vol_in + src) * (long)C + c0)); for (int j = 0; j < 4; ++j) xx[j] = (float)raw[j]; }
+        f32x4 xx;
+        { const bf16x4 raw = keep_if(xraw[ct], src >= 0 && c0 < C); for (int j = 0; j < 4; ++j) xx[j] = (float)raw[j]; }
         xv[ct] = xx;
         sum += xx[0] + xx[1] + xx[2] + xx[3];
     }
@@ -852,7 +867,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_bwd(MivpSwinDesc d, const bf16
     for (int ct = 0; ct < CT; ++ct) {
         const int c0 = 16 * ct + 4 * g;
         if (c0 < C) {
-            const bf16x4 raw = ld4(d_t1 + ti.tt * (long)C + c0);
+            const bf16x4 raw = t1raw[ct];
             f32x4 out;
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[j] = (float)raw[j] + rstd * (dyv[ct][j] - m1 - xv[ct][j] * m2);
@@ -1128,6 +1143,8 @@ extern "C" int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const vo
     const long T = (long)d->B * d->P * d->Nqp;
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
+    if (mivp_tok_wide_supported(d))                           // C = 96 / 192 / 384: column-split form (swin_tok_wide.hip)
+        return mivp_tok_wide_qkv_bwd(d, dq, dk, dv, x, tok_src, ln_w, wqkv_t, d_t1, dx, dn_out, st);
 #define L_QB(K) hipLaunchKernelGGL((k_swin_qkv_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dq, (const bf16_t*)dk, \
                                     (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, ln_b, (const bf16_t*)wqkv_t,             \
                                     (const bf16_t*)d_t1, (bf16_t*)dx, (bf16_t*)dn_out)

@@ -48,7 +48,6 @@ MIVP_DEV f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
 // per pack (10 + 4 VALU instructions per tile instead of 4, in a VALU-issue-bound loop).  Converting PAIRS and carrying
 // the result as two dwords keeps it at two instructions.  (Not inline asm: hipcc pads no VALU -> MFMA-operand wait states
 // around an asm statement, and a first asm form of this returned garbage on the large shapes.)
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 MIVP_DEV u32x2 pack4_pk(f32x4 v) {
@@ -72,6 +71,75 @@ using KR = OperandRows<32>;
 
 MIVP_DEV int oimg_off(int row, int byte) { return row * 32 + (byte ^ (((row >> 3) & 1) << 4)); }
 MIVP_DEV int exch_off(int tile, int key, int quad) { return tile * 512 + 128 * quad + 8 * (key ^ ((quad >> 1) << 3)); }
+
+// ---- staging of the query-side images (shared by the two kernels of this file) ----
+// A workgroup of these kernels runs ~10-15 us and a dependent global load -> LDS store round trip costs ~1 us at two
+// workgroups per CU.  Written as plain loops (one conditional load and one store per iteration, every conditional load in
+// its own basic block) the staging was a chain of ~12 such round trips: most of the kernel.  Here every load is
+// UNCONDITIONAL (clamped address, value replaced by zero afterwards), all of a thread's loads of a batch are issued before
+// its first LDS store, and the first batches of the Q' and dO / O images go out back to back.
+struct QSide {
+    const bf16_t *qb, *qa, *dob, *ob;
+    int Nqp, hd, hd4, A, a4, C;
+};
+// piece e of the Q' image: row e >> 3, 4-column group e & 7 = [head dims | bias one-hots | zero]
+MIVP_DEV bf16x4 q_piece(const QSide& s, int e) {
+    const int lrow = e >> 3, c4 = e & 7;
+    const int row = min(lrow, s.Nqp - 1);
+    const bool fq = c4 < s.hd4;
+    const int ca = min(c4 - s.hd4, s.a4 - 1);
+    const long to_qa = s.qa - s.qb;                            // (uniform) the two sources as one base + offset
+    const long off = sel(fq, (long)(row * s.hd + 4 * c4), to_qa + (long)(row * s.A + 4 * ca));
+    return keep_if(ld4(s.qb + off), lrow < s.Nqp && c4 < s.hd4 + s.a4);
+}
+// piece e of the dO image (row e >> 2, 4-column group e & 3) and the matching piece of O (for delta)
+MIVP_DEV void o_piece(const QSide& s, int e, bf16x4& gv, bf16x4& ov) {
+    const int lrow = e >> 2, c4 = e & 3;
+    const int row = min(lrow, s.Nqp - 1);
+    const int cc = min(c4, s.hd4 - 1);
+    const uint32_t off = (uint32_t)row * s.C + 4 * cc;
+    const bool ok = lrow < s.Nqp && c4 < s.hd4;
+    gv = keep_if(ld4(s.dob + off), ok);
+    ov = keep_if(ld4(s.ob + off), ok);
+}
+// four consecutive lanes share a query row; callers keep whole waves converged (the element count is a multiple of 64)
+MIVP_DEV void o_store(char* Oimg, float* del_s, int e, bf16x4 gv, bf16x4 ov) {
+    const int lrow = e >> 2, c4 = e & 3;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part += (float)gv[i] * (float)ov[i];
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    *reinterpret_cast<bf16x4*>(Oimg + oimg_off(lrow, 8 * c4)) = gv;
+    if (c4 == 0) del_s[lrow] = -part;                          // delta = sum_j dO * O, negated: the dP accumulators start from it
+}
+// One batch: UQ pieces of Q' and UO pieces of dO / O per thread, all loads before the first LDS store.  Indices beyond the
+// images are CLAMPED to the last piece for the loads AND the stores (whole waves at a time: the piece counts are multiples
+// of 64): a conditional store would pull its load into the conditional block, behind its own s_waitcnt vmcnt(0).
+template <int NTHR, int UQ, int UO>
+MIVP_DEV void stage_batch(const QSide& s, char* Qimg, char* Oimg, float* del_s, int q_elems, int o_elems, int eq0, int eo0) {
+    bf16x4 qv[UQ], gv[UO], ov[UO];
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) qv[u] = q_piece(s, min(eq0 + NTHR * u, q_elems - 1));
+#pragma unroll
+    for (int u = 0; u < UO; ++u) o_piece(s, min(eo0 + NTHR * u, o_elems - 1), gv[u], ov[u]);
+    __builtin_amdgcn_sched_barrier(0);                         // every load of the batch is out before the first store waits
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+        const int e = min(eq0 + NTHR * u, q_elems - 1);
+        *reinterpret_cast<bf16x4*>(Qimg + KR::off(e >> 3, 4 * (e & 7))) = qv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UO; ++u) o_store(Oimg, del_s, min(eo0 + NTHR * u, o_elems - 1), gv[u], ov[u]);
+}
+template <int NTHR>
+MIVP_DEV void stage_query_side(const QSide& s, char* Qimg, char* Oimg, float* del_s, int nq, int tid) {
+    constexpr int UQ = 6, UO = 3;                              // 7^3 windows (352 rows): the first batch is all there is
+    const int q_elems = nq * 8, o_elems = nq * 4;
+    stage_batch<NTHR, UQ, UO>(s, Qimg, Oimg, del_s, q_elems, o_elems, tid, tid);       // straight-line: joins the caller's loads
+    for (int b = 1; b * NTHR * UQ < q_elems; ++b)
+        stage_batch<NTHR, UQ, UO>(s, Qimg, Oimg, del_s, q_elems, o_elems, tid + b * NTHR * UQ, tid + b * NTHR * UO);
+}
 
 }  // namespace
 
@@ -119,61 +187,15 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     const float* lseb = lse + bph * (long)Nqp;
     const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
 
-    // ---------------- staging ----------------
-    // Q' rows: [head dims | bias one-hots | zero], 8-byte pieces
-    for (int e = tid; e < nq * 8; e += 64 * NW) {
-        const int lrow = e >> 3, c4 = e & 7;
-        bf16x4 val = zero4();
-        if (lrow < Nqp) {
-            if (c4 < hd4) val = ld4(qb + ((uint32_t)lrow * hd + 4 * c4));
-            else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)lrow * A + 4 * (c4 - hd4)));
-        }
-        *reinterpret_cast<bf16x4*>(Qimg + KR::off(lrow, 4 * c4)) = val;
-    }
-    // dO rows + delta = sum_j dO * O: four consecutive lanes share a query row (the loop bound is a multiple of the wave
-    // size, so the shuffles see converged waves)
-    for (int e = tid; e < nq * 4; e += 64 * NW) {
-        const int lrow = e >> 2, c4 = e & 3;
-        bf16x4 gv = zero4(), ov = zero4();
-        if (lrow < Nqp && c4 < hd4) {
-            gv = ld4(dob + ((uint32_t)lrow * C + 4 * c4));
-            ov = ld4(ob + ((uint32_t)lrow * C + 4 * c4));
-        }
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part += (float)gv[i] * (float)ov[i];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        *reinterpret_cast<bf16x4*>(Oimg + oimg_off(lrow, 8 * c4)) = gv;
-        if (c4 == 0) del_s[lrow] = -part;
-    }
-    for (int m = tid; m < nq; m += 64 * NW) {
-        const bool ok = m < Nqp;
-        lse_s[m] = ok ? -lseb[m] * MIVP_LOG2E : -INFINITY;    // the S accumulators start from it; padding query rows: P = 0
-        ridq[m] = (uint8_t)((ok && m < d.Nq) ? (MASKED ? tok_rid[pw * Nqp + m] : 0) : 255);
-    }
-    // K^T (head dims x keys): four consecutive keys of one 4-channel group, transposed 4x4 in registers.  The image has hd
-    // rows: lanes that would read rows hd..15 of the A operand re-read row 0 (row j of A only reaches row j of dQ^T, and
-    // rows >= hd are never stored).
-    for (int e = tid; e < (Nkp / 4) * hd4; e += 64 * NW) {
-        const int c4 = e % hd4, k4 = e / hd4;
-        bf16x4 in[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * k4 + i;
-            bf16x4 val = zero4();
-            if (row < Nqp) val = ld4(kb + ((uint32_t)row * hd + 4 * c4));
-            else if (row < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(row - Nqp) * hd + 4 * c4));
-            in[i] = val;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bf16x4 outv;
-            outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
-            *reinterpret_cast<bf16x4*>(Kt + (size_t)(4 * c4 + j) * KTROW + 2 * (4 * k4)) = outv;
-        }
-    }
-    // this wave's key tiles: K' / V fragments (B operands) from global, once
+    // ---------------- staging (see stage_query_side: unconditional loads, issued in batches) ----------------
+    const int max_prow = n_prompt_rows > 0 ? n_prompt_rows - 1 : 0;
+    // a row of [K ; Kp] / [V ; Vp] (clamped: rows beyond the prompts re-read the last one and are zeroed by the caller)
+    const long to_kp = kpb - kb, to_vp = vpb - vb, to_ka = kab - kb;       // (uniform) several sources as one base + offset
+    auto kv_off = [&](int row, int c4, long to_prompt) -> long {
+        const int pr = min(max(row - Nqp, 0), max_prow);
+        return sel(row < Nqp, (long)(row * hd + 4 * c4), to_prompt + (long)(pr * hd + 4 * c4));
+    };
+    // this wave's key tiles: K' / V fragments (B operands) from global, once -- issued first, used after the staging
     bf16x8 kf[FUSED_KPW];
     bf16x4 vf[FUSED_KPW];
     uint32_t kk[FUSED_KPW];                                    // mask operand: live = ((rq | pm) == kk), pm = kk's sign spread
@@ -183,43 +205,75 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     for (int i = 0; i < FUSED_KPW; ++i) {
         const int kt = wave + NW * i;
         const int krow = (kt < nt ? kt : 0) * 16 + r;
+        const bool staged = krow < Nqp + n_prompt_rows;
         bf16x4 piece[2];
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int c4 = 2 * g + hlf;
-            bf16x4 val = zero4();
-            if (c4 < hd4) {
-                if (krow < Nqp) val = ld4(kb + ((uint32_t)krow * hd + 4 * c4));
-                else if (krow < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
-            } else if (c4 < hd4 + a4) {
-                val = ld4(kab + ((uint32_t)krow * A + 4 * (c4 - hd4)));
-            }
-            piece[hlf] = val;
+            const int ca = min(max(c4 - hd4, 0), a4 - 1);
+            const long off = sel(c4 < hd4, kv_off(krow, min(c4, hd4 - 1), to_kp), to_ka + (long)(krow * A + 4 * ca));
+            piece[hlf] = keep_if(ld4(kb + off), sel(c4 < hd4, (int)staged, (int)(c4 < hd4 + a4)) != 0);
         }
         kf[i] = cat44(piece[0], piece[1]);
-        bf16x4 vv = zero4();
-        if (g < hd4) {
-            if (krow < Nqp) vv = ld4(vb + ((uint32_t)krow * hd + 4 * g));
-            else if (krow < Nqp + n_prompt_rows) vv = ld4(vpb + ((uint32_t)(krow - Nqp) * hd + 4 * g));
-        }
-        vf[i] = vv;
+        vf[i] = keep_if(ld4(vb + kv_off(krow, min(g, hd4 - 1), to_vp)), g < hd4 && staged);
         // content key: its region id; prompt and padding keys are never masked (padding keys are excluded by their bias)
         const bool content = krow < d.Nq;
-        const uint32_t cls = (MASKED && content) ? (uint32_t)tok_rid[pw * Nqp + krow] : 0u;
-        kk[i] = content ? cls : 0xFFFFFFFFu;
+        const uint32_t cls = MASKED ? (uint32_t)tok_rid[pw * Nqp + min(krow, d.Nq - 1)] : 0u;
+        kk[i] = (uint32_t)sel(content, (int)cls, -1);
         dkacc[i] = fzero4();
         dvacc[i] = fzero4();
         dsum[i] = f32x2{0.f, 0.f};
     }
+    // K^T (head dims x keys): four consecutive keys of one 4-channel group, transposed 4x4 in registers.  The image has hd
+    // rows: lanes that would read rows hd..15 of the A operand re-read row 0 (row j of A only reaches row j of dQ^T, and
+    // rows >= hd are never stored).  Loads here, stores after the query side's loads are out.
+    const int kt_elems = (Nkp / 4) * hd4;
+    auto kt_load = [&](int e, bf16x4 (&in)[4]) {
+        const int c4 = e % hd4, k4 = e / hd4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * k4 + i;
+            in[i] = keep_if(ld4(kb + kv_off(row, c4, to_kp)), row < Nqp + n_prompt_rows);
+        }
+    };
+    auto kt_store = [&](int e, const bf16x4 (&in)[4]) {
+        const int c4 = e % hd4, k4 = e / hd4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 outv;
+            outv[0] = in[0][j]; outv[1] = in[1][j]; outv[2] = in[2][j]; outv[3] = in[3][j];
+            *reinterpret_cast<bf16x4*>(Kt + (size_t)(4 * c4 + j) * KTROW + 2 * (4 * k4)) = outv;
+        }
+    };
+    bf16x4 kt_in[4];
+    kt_load(min(tid, kt_elems - 1), kt_in);
+    // lse (negated, log2 units: the S accumulators start from it; padding query rows: P = 0) and the query classes
+    const int m0 = min(tid, Nqp - 1);
+    const float lse0 = lseb[m0];
+    const int rid0 = MASKED ? tok_rid[pw * Nqp + m0] : 0;
+    const QSide qs{qb, qa, dob, ob, Nqp, hd, hd4, A, a4, C};
+    stage_query_side<64 * NW>(qs, Qimg, Oimg, del_s, nq, tid);
+    if (tid < kt_elems) kt_store(tid, kt_in);
+    for (int e = tid + 64 * NW; e < kt_elems; e += 64 * NW) { kt_load(e, kt_in); kt_store(e, kt_in); }
+    if (tid < nq) {
+        const bool ok = tid < Nqp;
+        lse_s[tid] = ok ? -lse0 * MIVP_LOG2E : -INFINITY;
+        ridq[tid] = (uint8_t)((ok && tid < d.Nq) ? rid0 : 255);
+    }
+    for (int m = tid + 64 * NW; m < nq; m += 64 * NW) {
+        const bool ok = m < Nqp;
+        lse_s[m] = ok ? -lseb[m] * MIVP_LOG2E : -INFINITY;
+        ridq[m] = (uint8_t)((ok && m < d.Nq) ? (MASKED ? tok_rid[pw * Nqp + m] : 0) : 255);
+    }
+    __syncthreads();
     // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op
     bool cut = false;
     if (MASKED) {
-        const int first = tok_rid[pw * Nqp];
+        const uint8_t first = ridq[0];
         int differs = 0;
-        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= tok_rid[pw * Nqp + m] != first;
+        for (int m = tid; m < d.Nq; m += 64 * NW) differs |= ridq[m] != first;
         cut = __syncthreads_or(differs) != 0;
     }
-    __syncthreads();
 
     const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
     const char* ktrow = Kt + (size_t)(r < hd ? r : 0) * KTROW;  // this lane's row of the dQ product's A operand
@@ -351,6 +405,147 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prompt-only form for the FIRST prompted block behind a frozen stem (no data gradient is needed there: only the prompt
+// keys' dKp / dVp partials and the prompt-bias column sums).  KP = Npp / 16 prompt key tiles (1, 2, 4 or 8): wave w owns
+// prompt tile w % KP and the query tiles of part w / KP (8 / KP parts); no dS exchange, no dQ, no barrier in the loop.  The
+// parts' accumulators meet in LDS at the end (fixed order).  Replaces mivp_win_attn_delta + the prompt-only mode of
+// mivp_win_attn_bwd_dkv (which staged every query for four key tiles: 141 us -> see profiles/).
+// ---------------------------------------------------------------------------------------------
+template <int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_prompt(
+    MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
+    const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+    const float* __restrict__ lse, float* __restrict__ dkp_part, float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int C = d.C, heads = d.heads, hd = C / heads, Nqp = d.Nqp, Nkp = d.Nkp, A = d.augp;
+    const int hd4 = hd / 4, a4 = A / 4;
+    const long bph = blockIdx.x;
+    const int head = (int)(bph % heads);
+    const long bp = bph / heads;
+    const int nqt = Nqp / 16;
+    const int nq = nqt * 16;
+    const int KP = d.Npp / 16, parts = NW / KP;
+    char* Qimg = smem;
+    char* Oimg = Qimg + (size_t)nq * 64;
+    float* lse_s = reinterpret_cast<float*>(Oimg + (size_t)nq * 32);
+    float* del_s = lse_s + nq;
+    float* red = del_s + nq;                                  // [NW][2][256] + [NW][64] partial accumulators
+    const bf16_t* qb = q + bph * (long)Nqp * hd;
+    const bf16_t* kpb = kp + (long)head * d.Npp * hd;
+    const bf16_t* vpb = vp + (long)head * d.Npp * hd;
+    const bf16_t* kab = ka + (long)head * Nkp * A;
+    const bf16_t* dob = d_o + bp * (long)Nqp * C + head * hd;
+    const bf16_t* ob = o + bp * (long)Nqp * C + head * hd;
+    const float* lseb = lse + bph * (long)Nqp;
+    // this wave's prompt key tile (loads first, used after the staging)
+    const int pt = wave % KP, part = wave / KP;
+    const int trow = pt * 16 + r;                             // row of Kp / Vp
+    bf16x4 piece[2];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const int c4 = 2 * g + hlf;
+        const int ca = min(max(c4 - hd4, 0), a4 - 1);
+        const long to_ka = kab - kpb;
+        const long off = sel(c4 < hd4, (long)(trow * hd + 4 * min(c4, hd4 - 1)), to_ka + (long)((Nqp + trow) * A + 4 * ca));
+        piece[hlf] = keep_if(ld4(kpb + off), c4 < hd4 + a4);
+    }
+    const bf16x8 kf = cat44(piece[0], piece[1]);
+    const bf16x4 vf = keep_if(ld4(vpb + ((uint32_t)trow * hd + 4 * min(g, hd4 - 1))), g < hd4);
+    const int m0 = min(tid, nq - 1);
+    const float lse0 = lseb[m0];
+    const QSide qs{qb, qa, dob, ob, Nqp, hd, hd4, A, a4, C};
+    stage_query_side<64 * NW>(qs, Qimg, Oimg, del_s, nq, tid);
+    if (tid < nq) lse_s[tid] = -lse0 * MIVP_LOG2E;
+    for (int m = tid + 64 * NW; m < nq; m += 64 * NW) lse_s[m] = -lseb[m] * MIVP_LOG2E;
+    f32x4 dkacc = fzero4(), dvacc = fzero4();
+    f32x2 dsum = {0.f, 0.f};
+    __syncthreads();
+    const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
+    const char* q_rd = Qimg + KR::off(r, 8 * g);
+    const char* q_tr = Qimg + KR::off(4 * g + (r >> 2), 4 * (r & 3));
+    const char* o_rd = Oimg + oimg_off(r, 8 * g);
+    const char* o_tr = Oimg + oimg_off(4 * g + (r >> 2), 8 * (r & 3));
+    const int t_begin = part * nqt / parts, t_end = (part + 1) * nqt / parts;
+    for (int t = t_begin; t < t_end; ++t) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
+        const f32x4 n4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_rd + 1024 * t);
+        const bf16x4 of = *reinterpret_cast<const bf16x4*>(o_rd + 512 * t);
+        const bf16x4 qt = tr_read(q_tr + 1024 * t);
+        const bf16x4 ot = tr_read(o_tr + 512 * t);
+        const f32x4 s = mfma16(qf, kf, l4);                   // prompt keys are never masked
+        const f32x4 dp = mfma16k16(of, vf, DROP ? fzero4() : n4);
+        f32x4 pv, ds;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float keep = 1.f;
+            if (DROP) {
+                const int krow = Nqp + trow;
+                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
+            }
+            const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
+            const float pe = __builtin_amdgcn_exp2f(s[j]);
+            pv[j] = DROP ? pe * keep : pe;
+            ds[j] = pe * dpe;
+        }
+        dsum = dsum + (f32x2{ds[0], ds[1]} + f32x2{ds[2], ds[3]});
+        dkacc = mfma16k16(qt, pack4_pk(ds), dkacc);
+        dvacc = mfma16k16(ot, pack4_pk(pv), dvacc);
+    }
+    // add the parts (fixed order), store this (window, head)'s partials
+    float* mine = red + (size_t)wave * 576;
+    *reinterpret_cast<f32x4*>(mine + r * 16 + 4 * g) = dkacc;
+    *reinterpret_cast<f32x4*>(mine + 256 + r * 16 + 4 * g) = dvacc;
+    mine[512 + lane] = dsum[0] + dsum[1];
+    __syncthreads();
+    if (part == 0) {
+        f32x4 ak = fzero4(), av = fzero4();
+        float at = 0.f;
+        for (int pp = 0; pp < parts; ++pp) {
+            const float* src = red + (size_t)(pt + KP * pp) * 576;
+            ak = ak + *reinterpret_cast<const f32x4*>(src + r * 16 + 4 * g);
+            av = av + *reinterpret_cast<const f32x4*>(src + 256 + r * 16 + 4 * g);
+            at += src[512 + lane];
+        }
+        at = col_sum(at);
+        if (4 * g < hd) {
+            *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + trow) * (long)hd + 4 * g)) = ak;
+            *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + trow) * (long)hd + 4 * g)) = av;
+        }
+        if (g == 0) dtok_part[bph * d.Npp + trow] = at;
+    }
+}
+
+extern "C" int mivp_win_attn_bwd_prompt_supported(const MivpSwinDesc* d) {
+    if (!d || d->heads <= 0 || d->C % d->heads || d->Np <= 0) return 0;
+    const int hd = d->C / d->heads, kp = d->Npp / 16;
+    int dks, nt;
+    if (mivp_attn_tile_config(d, &dks, &nt) || dks != 1) return 0;
+    if (hd > 16 || hd % 4 || d->augp < 4 || !(kp == 1 || kp == 2 || kp == 4 || kp == 8) || d->Nqp % 16) return 0;
+    const size_t lds = (size_t)d->Nqp * 96 + 2 * (size_t)d->Nqp * 4 + 8 * 576 * 4;
+    return lds <= 78 * 1024 ? 1 : 0;
+}
+
+extern "C" int mivp_win_attn_bwd_prompt(const MivpSwinDesc* d, const void* q, const void* kp, const void* vp, const void* qa,
+                                        const void* ka, const void* o, const void* d_o, const float* lse, float* dkp_part,
+                                        float* dvp_part, float* dtok_part, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && q && kp && vp && qa && ka && o && d_o && lse && dkp_part && dvp_part && dtok_part);
+    if (!mivp_win_attn_bwd_prompt_supported(d)) { mivp_set_error("win_attn_bwd_prompt: shape outside the kernel's range"); return MIVP_EUNSUPPORTED; }
+    const size_t lds = (size_t)d->Nqp * 96 + 2 * (size_t)d->Nqp * 4 + 8 * 576 * 4;
+    constexpr int NW = 8;
+    auto kern = d->attn_drop_thr ? k_win_attn_bwd_prompt<NW, true> : k_win_attn_bwd_prompt<NW, false>;
+    MIVP_LDS_OPT_IN(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, (hipStream_t)stream, *d,
+                       (const bf16_t*)q, (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka,
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse, dkp_part, dvp_part, dtok_part);
+    return mivp_check_launch("win_attn_bwd_prompt");
+}
+
 static size_t fused_lds_bytes(const MivpSwinDesc* d) {
     const size_t nq = (size_t)((d->Nqp + 31) / 32 * 2) * 16, nt = d->Nkp / 16;
     const size_t hd = d->C / d->heads;
@@ -364,7 +559,7 @@ extern "C" int mivp_win_attn_bwd_fused_supported(const MivpSwinDesc* d) {
     const int hd = d->C / d->heads;
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt) || dks != 1) return 0;
-    if (hd > 16 || hd % 4 || d->Nkp / 16 > 8 * FUSED_KPW) return 0;
+    if (hd > 16 || hd % 4 || d->augp < 4 || d->Nq < 1 || d->Nkp / 16 > 8 * FUSED_KPW) return 0;
     return fused_lds_bytes(d) <= 160 * 1024 ? 1 : 0;
 }
 

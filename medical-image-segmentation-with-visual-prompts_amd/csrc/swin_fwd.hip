@@ -90,18 +90,13 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
     auto slab_fetch = [&](int nt) {
 #pragma unroll
         for (int u = 0; u < PCS; ++u) {
-            const int p = threadIdx.x + 256 * u;
-            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
-            const int nrow = 16 * nt + row, c = 32 * sub + 8 * ch;
-            wreg[u] = (p < 64 * KS && nrow < n_out && c < C) ? ld8(wqkv + (long)nrow * C + c) : zero8();
+            wreg[u] = ld8(wqkv + (long)nt * KS * 512 + 8 * min((int)threadIdx.x + 256 * u, 64 * KS - 1));    // fragment image: a linear copy
         }
     };
     auto slab_store = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < PCS; ++u) {
-            const int p = threadIdx.x + 256 * u;
-            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
-            if (p < 64 * KS) *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + sub * 1024 + WR::off(row, 8 * ch)) = wreg[u];
+            *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + 16 * min((int)threadIdx.x + 256 * u, 64 * KS - 1)) = wreg[u];
         }
     };
     if (LDSW && nt_begin < nt_end) { slab_fetch(nt_begin); slab_store(0); __syncthreads(); }
@@ -117,7 +112,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
             const char* slab = wsm + cur * KS * 1024;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slab + s * 1024 + WR::off(r, 8 * g));
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slab + s * 1024 + 16 * lane);
                 acc0 = mfma16(a, xb[0][s], acc0);
                 acc1 = mfma16(a, xb[1][s], acc1);
             }
@@ -126,9 +121,7 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int c = 32 * s + 8 * g;
-                bf16x8 a = zero8();
-                if (nrow < n_out && c < C) a = ld8(wqkv + (long)nrow * C + c);
+                const bf16x8 a = wfrag(wqkv, KS, nt, s, lane);
                 acc0 = mfma16(a, xb[0][s], acc0);
                 acc1 = mfma16(a, xb[1][s], acc1);
             }
@@ -559,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
 //   32-deep k-step and reading the weight row in the same permuted k order.
 // ---------------------------------------------------------------------------------------------
 template <int CT>
-__global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 4 : 5)) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const bf16_t* __restrict__ o,
                                                            const bf16_t* __restrict__ x,
                                                            const int* __restrict__ tok_src, const int* __restrict__ tok_dst,
                                                            const bf16_t* __restrict__ wproj, const float* __restrict__ bproj,
@@ -586,24 +579,20 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
     const int slot = (int)(tt - bpu * (unsigned)d.Nqp);
     const int pw = (int)(bpu % (unsigned)d.P);
     const long b = bpu / (unsigned)d.P;
-    const int src = live ? tok_src[pw * d.Nqp + slot] : -2;
-    const int dst = live ? tok_dst[pw * d.Nqp + slot] : -1;
+    const int src = sel(live, tok_src[pw * d.Nqp + slot], -2);       // (a dead lane decodes as token 0: the address is valid)
+    const int dst = sel(live, tok_dst[pw * d.Nqp + slot], -1);
+    // Loads are unconditional (clamped address, masked value) and batched: common.hpp "Branch-free loads".
     bf16x8 wreg[PCS];
     auto slab_fetch = [&](const bf16_t* __restrict__ w, int nt) {
 #pragma unroll
         for (int u = 0; u < PCS; ++u) {
-            const int p = threadIdx.x + 256 * u;
-            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
-            const int nrow = 16 * nt + row, c = 32 * sub + 8 * ch;
-            wreg[u] = (p < 64 * KS && nrow < C && c < C) ? ld8(w + (long)nrow * C + c) : zero8();
+            wreg[u] = ld8(w + (long)nt * KS * 512 + 8 * min((int)threadIdx.x + 256 * u, 64 * KS - 1));        // fragment image: a linear copy
         }
     };
     auto slab_store = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < PCS; ++u) {
-            const int p = threadIdx.x + 256 * u;
-            const int sub = p >> 6, row = (p & 63) >> 2, ch = p & 3;
-            if (p < 64 * KS) *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + sub * 1024 + WR::off(row, 8 * ch)) = wreg[u];
+            *reinterpret_cast<bf16x8*>(wsm + buf * KS * 1024 + 16 * min((int)threadIdx.x + 256 * u, 64 * KS - 1)) = wreg[u];
         }
     };
 
@@ -611,8 +600,12 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int c = 32 * s + 8 * g;
-        ob[s] = (live && c < C) ? ld8(o + (tt * (long)C + c)) : zero8();
+        ob[s] = keep_if(ld8(o + (tt * (long)C + min(c, C - 8))), live && c < C);
     }
+    bf16x4 xraw[CT];                                             // the shortcut row (one round trip behind tok_src)
+    const long xrow = (b * d.vol_in + max(src, 0)) * (long)C;
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) xraw[nt] = ld4(x + xrow + min(16 * nt + 4 * g, C - 4));
     // GEMM1: t1 = o Wproj^T + b + shortcut
     f32x4 t1[CT];
     float sum = 0.f;
@@ -626,22 +619,20 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
             const char* slab = wsm + (nt & 1) * KS * 1024;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                acc = mfma16(*reinterpret_cast<const bf16x8*>(slab + s * 1024 + WR::off(r, 8 * g)), ob[s], acc);
+                acc = mfma16(*reinterpret_cast<const bf16x8*>(slab + s * 1024 + 16 * lane), ob[s], acc);
             if (nt + 1 < CT) slab_store((nt + 1) & 1);        // that buffer was last read in iteration nt-1
             __syncthreads();
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int c = 32 * s + 8 * g;
-                bf16x8 a = zero8();
-                if (nrow < C && c < C) a = ld8(wproj + (long)nrow * C + c);
-                acc = mfma16(a, ob[s], acc);
+                acc = mfma16(wfrag(wproj, KS, nt, s, lane), ob[s], acc);
             }
         }
         const int n0 = 16 * nt + 4 * g;
+        const f32x4 bp4 = *reinterpret_cast<const f32x4*>(bproj + min(n0, C - 4));
         if (n0 < C) {
-            f32x4 sc = fzero4();
-            if (src >= 0) { bf16x4 xv = ld4(x + ((b * d.vol_in + src) * (long)C + n0)); for (int j = 0; j < 4; ++j) sc[j] = (float)xv[j]; }
+            f32x4 sc;
+            { const bf16x4 xv = keep_if(xraw[nt], src >= 0); for (int j = 0; j < 4; ++j) sc[j] = (float)xv[j]; }
             f32x4 keep = {1.f, 1.f, 1.f, 1.f};
             if (d.proj_drop_thr) {                           // proj dropout: on proj(o) + b, before the residual
                 const uint32_t pi = (uint32_t)((tt * C + n0) >> 1);
@@ -653,7 +644,7 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float val = (float)(bf16_t)((acc[j] + bproj[n0 + j]) * keep[j] + sc[j]);   // t1 lives as bf16
+                const float val = (float)(bf16_t)((acc[j] + bp4[j]) * keep[j] + sc[j]);   // t1 lives as bf16
                 acc[j] = val;
                 sum += val;
             }
@@ -679,10 +670,11 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
         bf16x4 yy = zero4();
         if (nt < CT) {
             const int n0 = 16 * nt + 4 * g;
-            if (n0 < C) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(ln_w + min(n0, C - 4));
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(ln_b + min(n0, C - 4));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) yy[j] = (bf16_t)((t1[nt][j] - mean) * rstd * ln_w[n0 + j] + ln_b[n0 + j]);
-            }
+            for (int j = 0; j < 4; ++j) yy[j] = (bf16_t)((t1[nt][j] - mean) * rstd * w4[j] + b4[j]);
+            yy = keep_if(yy, n0 < C);
         }
         y2[nt] = yy;
     }
@@ -698,28 +690,22 @@ __global__ __launch_bounds__(256) void k_swin_proj_mlp_fwd(MivpSwinDesc d, const
             const char* slab = wsm + (mt & 1) * KS * 1024;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(slab + s * 1024 + WR::off(r, 4 * g));
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(slab + s * 1024 + WR::off(r, 16 + 4 * g));
-                acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
+                // (paired image: the fragment is already lo | hi)
+                acc = mfma16(*reinterpret_cast<const bf16x8*>(slab + s * 1024 + 16 * lane), cat44(y2[2 * s], y2[2 * s + 1]), acc);
             }
             if (mt + 1 < CT) slab_store((mt + 1) & 1);
             __syncthreads();
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                bf16x4 lo = zero4(), hi = zero4();
-                const int c0 = 32 * s + 4 * g, c1 = 32 * s + 16 + 4 * g;
-                if (nrow < C) {
-                    if (c0 < C) lo = ld4(wmlp + (long)nrow * C + c0);
-                    if (c1 < C) hi = ld4(wmlp + (long)nrow * C + c1);
-                }
-                acc = mfma16(cat44(lo, hi), cat44(y2[2 * s], y2[2 * s + 1]), acc);
+                acc = mfma16(wfrag(wmlp, KS, mt, s, lane), cat44(y2[2 * s], y2[2 * s + 1]), acc);
             }
         }
         const int n0 = 16 * mt + 4 * g;
+        const f32x4 bm4 = *reinterpret_cast<const f32x4*>(bmlp + min(n0, C - 4));
         if (n0 < C && dst >= 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += t1[mt][j] + bmlp[n0 + j];
+            for (int j = 0; j < 4; ++j) acc[j] += t1[mt][j] + bm4[j];
             st4(y + ((b * d.vol_out + dst) * (long)C + n0), pack4(acc));
         }
     }

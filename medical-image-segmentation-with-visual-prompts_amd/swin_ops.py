@@ -25,8 +25,8 @@ class SwinBlockWeights:
     heads: int
     ln1_w: torch.Tensor
     ln1_b: torch.Tensor
-    wqkv: torch.Tensor          # bf16 [3C, C]
-    wproj: torch.Tensor         # bf16 [C, C]
+    wqkv: torch.Tensor          # bf16 [3C, C] row-major (prompt K/V kernels)
+    wproj: torch.Tensor         # bf16 [C, C]  row-major
     bproj: torch.Tensor
     ln2_w: torch.Tensor
     ln2_b: torch.Tensor
@@ -36,10 +36,32 @@ class SwinBlockWeights:
     t_w: torch.Tensor
     t_d: torch.Tensor
     ts: Optional[torch.Tensor]  # f32 [heads, Np], already * embed_dim**-0.5
-    wqkv_t: Optional[torch.Tensor] = None    # bf16 [C, 3C]   (backward)
-    wproj_t: Optional[torch.Tensor] = None   # bf16 [C, C]
+    wqkv_f: Optional[torch.Tensor] = None    # fragment images (pack_weight_frags) read by the token kernels: forward
+    wproj_f: Optional[torch.Tensor] = None
+    wmlp_f: Optional[torch.Tensor] = None    # paired k order
+    wqkv_t: Optional[torch.Tensor] = None    # ... backward: images of the transposes ([C, 3C], [C, C], [C, C] paired)
+    wproj_t: Optional[torch.Tensor] = None
     wmlp_t: Optional[torch.Tensor] = None
     aug_cache: Optional[dict] = None         # (Nqp, Nkp, augp) -> (qa, ka) for prompt-free calls (constants of the weights)
+
+
+def pack_weight_frags(wm: torch.Tensor, paired: bool = False, k_steps: int = 0) -> torch.Tensor:
+    """Row-major [R, K] bf16 -> the MFMA-fragment-major image the token kernels read (mivp.h "weight fragment images"):
+    [R/16 row tiles][K/32 k-steps][64 lanes][8], rows padded to 16 and K to 32 with zeros.  Lane (r, g) = 16 g + r of
+    (row tile nt, k-step s) holds W[16 nt + r][32 s + 8 g .. + 8], or with ``paired`` the two 4-element groups
+    W[..][32 s + 4 g .. + 4] | W[..][32 s + 16 + 4 g .. + 4] (the k order of a GEMM whose B operand is the previous GEMM's
+    accumulator).  A wave's A fragment is then 1 KB contiguous: one fully coalesced load instead of 64 scattered 16-byte
+    ones (the texture-address unit spends about a cycle per cache line touched -- DESIGN.md, r02 TA counters)."""
+    R, K = wm.shape
+    Rp, Kp = (R + 15) // 16 * 16, max((K + 31) // 32, k_steps) * 32     # k_steps: the kernel's count when it exceeds ceil(K / 32)
+    if (Rp, Kp) != (R, K):
+        wp = torch.zeros((Rp, Kp), dtype=wm.dtype, device=wm.device)
+        wp[:R, :K] = wm
+    else:
+        wp = wm.contiguous()
+    if paired:                                           # [nt][r][s][half][g][e] -> [nt][s][g][r][half][e]
+        return wp.view(Rp // 16, 16, Kp // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()
+    return wp.view(Rp // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()      # [nt][r][s][g][e] -> [nt][s][g][r][e]
 
 
 def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=False) -> SwinBlockWeights:
@@ -57,10 +79,14 @@ def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=
         wproj=f("attn.proj.weight").to(BF16).contiguous(), bproj=f("attn.proj.bias"),
         ln2_w=f("mlp_norm.weight"), ln2_b=f("mlp_norm.bias"), wmlp=f("mlp.weight").to(BF16).contiguous(),
         bmlp=f("mlp.bias"), t_h=tabs[0], t_w=tabs[1], t_d=tabs[2], ts=ts)
+    w.wqkv_f = pack_weight_frags(w.wqkv)
+    w.wproj_f = pack_weight_frags(w.wproj)
+    w.wmlp_f = pack_weight_frags(w.wmlp, paired=True)
     if need_bwd:
-        w.wqkv_t = w.wqkv.t().contiguous()
-        w.wproj_t = w.wproj.t().contiguous()
-        w.wmlp_t = w.wmlp.t().contiguous()
+        ct = (w.wqkv.shape[1] + 15) // 16                # k_swin_qkv_bwd<CT> walks ceil(3 * 16 CT / 32) k-steps (C = 8: two)
+        w.wqkv_t = pack_weight_frags(w.wqkv.t(), k_steps=(3 * 16 * ct + 31) // 32)
+        w.wmlp_t = pack_weight_frags(w.wmlp.t())
+        w.wproj_t = pack_weight_frags(w.wproj.t(), paired=True)
     return w
 
 
@@ -138,7 +164,7 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     q = torch.empty((BP, w.heads, d.Nqp, hd), dtype=BF16, device=dev)
     k = torch.empty_like(q)
     v = torch.empty_like(q)
-    L.call("mivp_swin_qkv_fwd", C.byref(d), L.ptr(x), L.ptr(tb.tok_src), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
+    L.call("mivp_swin_qkv_fwd", C.byref(d), L.ptr(x), L.ptr(tb.tok_src), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv_f),
            L.ptr(q), L.ptr(k), L.ptr(v), st)
     kp = vp = None
     if n_prompt:
@@ -166,8 +192,8 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
            L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
     t1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if save else None
     y = torch.empty_like(x)
-    L.call("mivp_swin_proj_mlp_fwd", C.byref(d), L.ptr(o), L.ptr(x), L.ptr(tb.tok_src), L.ptr(tb.tok_dst), L.ptr(w.wproj),
-           L.ptr(w.bproj), L.ptr(w.ln2_w), L.ptr(w.ln2_b), L.ptr(w.wmlp), L.ptr(w.bmlp), L.ptr(t1), L.ptr(y), st)
+    L.call("mivp_swin_proj_mlp_fwd", C.byref(d), L.ptr(o), L.ptr(x), L.ptr(tb.tok_src), L.ptr(tb.tok_dst), L.ptr(w.wproj_f),
+           L.ptr(w.bproj), L.ptr(w.ln2_w), L.ptr(w.ln2_b), L.ptr(w.wmlp_f), L.ptr(w.bmlp), L.ptr(t1), L.ptr(y), st)
     if save:
         return y, SwinSaved(d, tb, x, q, k, v, kp, vp, qa, ka, o, lse, t1)
     return y, None
@@ -261,6 +287,11 @@ def swin_block_backward(sv: SwinSaved, w: SwinBlockWeights, prompt: Optional[tor
         L.call("mivp_win_attn_bwd_fused", C.byref(d), L.ptr(sv.q), L.ptr(sv.k), L.ptr(sv.v), L.ptr(sv.kp), L.ptr(sv.vp),
                L.ptr(sv.qa), L.ptr(sv.ka), L.ptr(tb.tok_rid), L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(dq), L.ptr(dk),
                L.ptr(dv), L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), st)
+    elif (not need_dx and has_prompt and need_prompt and USE_FUSED_ATTN_BWD
+          and bool(L.lib().mivp_win_attn_bwd_prompt_supported(C.byref(d)))):
+        # first prompted block behind a frozen stem: only the prompt keys' partials (one launch, forms delta itself)
+        L.call("mivp_win_attn_bwd_prompt", C.byref(d), L.ptr(sv.q), L.ptr(sv.kp), L.ptr(sv.vp), L.ptr(sv.qa), L.ptr(sv.ka),
+               L.ptr(sv.o), L.ptr(d_o), L.ptr(sv.lse), L.ptr(dkp_part), L.ptr(dvp_part), L.ptr(dtok_part), st)
     else:
         delta = torch.empty((BP, heads, d.Nqp), dtype=torch.float32, device=dev)
         if need_dx:

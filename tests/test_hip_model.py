@@ -89,6 +89,7 @@ def test_downstream_forward_backward(tag):
     params_p = dict(model_p.named_parameters())
     assert sorted(k for k, q in params.items() if q.requires_grad) == sorted(fx.meta["trainable"])
     bad = {}
+    worst = (0.0, "")
     for k in fx.meta["trainable"]:
         g, w = params[k].grad, osd[k].grad
         assert g is not None, k
@@ -102,6 +103,8 @@ def test_downstream_forward_backward(tag):
         # the direction check only means something where the gradient itself is stable under bf16-level noise
         if (yard < 0.2 and cos < 0.9) or e > max(5e-2, 3.0 * yard):
             bad[k] = (e, cos, yard)
+        worst = max(worst, (e / max(5e-2, 3.0 * yard), k))
+    print(f"[grad margins] {tag}: worst error / bar = {worst[0]:.2f} at {worst[1]}")
     assert not bad, bad
     # frozen BatchNorms still ran in train mode: running statistics moved exactly as the reference's
     msd = model.state_dict()

@@ -367,3 +367,45 @@ def test_one_pass_backward_equals_two_pass(window, dims, C, heads, n_prompt, shi
     if n_prompt:
         assert rel_l2(dp1.cpu(), dp2.cpu()) < 1e-3 and rel_l2(dt1.cpu(), dt2.cpu()) < 1e-3, \
             (rel_l2(dp1.cpu(), dp2.cpu()), rel_l2(dt1.cpu(), dt2.cpu()))
+
+
+@pytest.mark.parametrize("window,dims,C,heads,n_prompt,shift,dropout", [
+    ((7, 7, 7), (24, 24, 24), 48, 4, 64, (0, 0, 0), None),            # cfg2's first prompted block (padded windows)
+    ((7, 7, 7), (14, 14, 14), 48, 4, 64, (3, 3, 3), (0.1, 0.0, 5, 6)),
+    ((4, 4, 4), (8, 8, 8), 32, 2, 16, (0, 0, 0), None),               # one prompt tile: eight query parts
+    ((5, 5, 3), (10, 10, 6), 48, 4, 30, (2, 2, 1), None),             # 30 prompts -> two prompt tiles, the second ragged
+])
+def test_prompt_only_backward_equals_two_pass(window, dims, C, heads, n_prompt, shift, dropout):
+    """mivp_win_attn_bwd_prompt (first prompted block behind a frozen stem: need_dx False) against mivp_win_attn_delta + the
+    prompt-only mode of mivp_win_attn_bwd_dkv: same products, same bf16 rounding points of dS / P."""
+    import ctypes
+    import mivp_amd
+    from mivp_amd import swin_ops, _lib as L
+    from oracle.unetr_ref import _block_state
+    gen = torch.Generator().manual_seed(4)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, n_prompt, True, gen)
+    sd = _rounded_state(sd)
+    x = r16(torch.randn(2, C, *dims, generator=gen))
+    prm = 0.5 * torch.randn(n_prompt, C, generator=gen)
+    gout = r16(torch.randn(2, C, *dims, generator=gen))
+    w = swin_ops.weights_from_state(sd, "", heads, 64, n_prompt, torch.device(DEV), need_bwd=True)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = prm.to(DEV)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        swin_ops.USE_FUSED_ATTN_BWD = fused
+        try:
+            y, saved = swin_ops.swin_block_forward(xc, pd, w, None, window, shift, save=True, dropout=dropout)
+            if fused:
+                assert L.lib().mivp_win_attn_bwd_prompt_supported(ctypes.byref(saved.desc)) == 1
+            res.append(swin_ops.swin_block_backward(saved, w, pd, dy, False, True))
+        finally:
+            swin_ops.USE_FUSED_ATTN_BWD = True
+    torch.cuda.synchronize()
+    (dx1, dp1, dt1), (dx2, dp2, dt2) = res
+    assert dx1 is None and dx2 is None
+    assert torch.isfinite(dp1).all() and torch.isfinite(dt1).all()
+    assert rel_l2(dp1.cpu(), dp2.cpu()) < 1e-3 and rel_l2(dt1.cpu(), dt2.cpu()) < 1e-3, \
+        (rel_l2(dp1.cpu(), dp2.cpu()), rel_l2(dt1.cpu(), dt2.cpu()))
