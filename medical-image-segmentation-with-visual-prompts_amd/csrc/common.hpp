@@ -129,8 +129,8 @@ MIVP_DEV bf16x8 keep_if(bf16x8 v, bool ok) {
 }
 struct FastDiv {
     uint32_t m, d;
-    MIVP_DEV explicit FastDiv(int div) : m(0xFFFFFFFFu / (uint32_t)div + 1u), d((uint32_t)div) {}
-    MIVP_DEV int div(int n) const { return (int)__umulhi((uint32_t)n, m); }          // exact for 0 <= n < 2^16, d < 2^16
+    MIVP_DEV explicit FastDiv(int div) : m(0xFFFFFFFFu / (uint32_t)div + 1u), d((uint32_t)div) {}      // (d == 1: m wraps to 0)
+    MIVP_DEV int div(int n) const { return d == 1u ? n : (int)__umulhi((uint32_t)n, m); }   // exact for 0 <= n < 2^16, d < 2^16
     MIVP_DEV int mod(int n) const { return n - div(n) * (int)d; }
 };
 

@@ -11,8 +11,12 @@
 int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
 // swin_tok_wide.hip: the column-split token kernels of the wide stages
 int mivp_tok_wide_supported(const MivpSwinDesc* d);
+int mivp_tok_rows_supported(const MivpSwinDesc* d);
+long mivp_tok_natural_offset(int C);
 int mivp_tok_wide_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x, const int32_t* tok_src,
                           const float* ln_w, const void* wqkv_t, const void* d_t1, void* dx, void* dn_out, hipStream_t st);
+int mivp_tok_wide_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1, const float* ln_w,
+                               const void* wmlp_t, const void* wproj_t, void* d_o, void* d_t1, hipStream_t st);
 
 namespace {
 
@@ -1003,6 +1007,10 @@ extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, con
     const long T = (long)d->B * d->P * d->Nqp;
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
+    // C = 48 / 96 / 192 / 384, no proj dropout, no weight-gradient outputs: row-image kernel, natural-order image of wproj_t
+    if (mivp_tok_rows_supported(d) && !d->proj_drop_thr && !dn_out && !dyw && !d_pj)
+        return mivp_tok_wide_proj_mlp_bwd(d, dy, tok_dst, t1, ln_w, wmlp_t, (const bf16_t*)wproj_t + mivp_tok_natural_offset(d->C),
+                                          d_o, d_t1, st);
 #define L_PMB(K) hipLaunchKernelGGL((k_swin_proj_mlp_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, tok_dst, \
                                      (const bf16_t*)t1, ln_w, ln_b, (const bf16_t*)wmlp_t, (const bf16_t*)wproj_t,          \
                                      (bf16_t*)d_o, (bf16_t*)d_t1, (bf16_t*)dn_out, (bf16_t*)dyw, (bf16_t*)d_pj)

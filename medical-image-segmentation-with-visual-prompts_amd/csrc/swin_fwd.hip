@@ -3,6 +3,16 @@
 // multi_head_attention/window_attention.py:35-61, relative_positional_encoding.py:99-142.
 #include "common.hpp"
 
+// swin_tok_wide.hip: the column-split token kernels of the wide stages
+int mivp_tok_wide_supported(const MivpSwinDesc* d);
+int mivp_tok_rows_supported(const MivpSwinDesc* d);
+long mivp_tok_natural_offset(int C);
+int mivp_tok_wide_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_src, const float* ln_w, const float* ln_b,
+                          const void* wqkv, void* q, void* k, void* v, hipStream_t st);
+int mivp_tok_wide_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x, const int32_t* tok_src, const int32_t* tok_dst,
+                               const void* wproj, const float* bproj, const float* ln_w, const float* ln_b, const void* wmlp,
+                               const float* bmlp, void* t1_out, void* y, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 // K1a  gather + LayerNorm + QKV
 //   one wave = 32 tokens (two 16-token B tiles) so that every weight fragment fetched from L2
@@ -734,6 +744,7 @@ extern "C" int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int
     int rc = swin_common_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(x && tok_src && ln_w && ln_b && wqkv && q && k && v);
+    if (mivp_tok_wide_supported(d)) return mivp_tok_wide_qkv_fwd(d, x, tok_src, ln_w, ln_b, wqkv, q, k, v, (hipStream_t)stream);
     const long T = (long)d->B * d->P * d->Nqp;
     const unsigned gx = (unsigned)((T + 127) / 128);
     const int KS = (d->C + 31) / 32;
@@ -851,6 +862,10 @@ extern "C" int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, cons
     const unsigned grid = (unsigned)((T + 63) / 64);
     const int CT = (d->C + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
+    // C = 48 / 96 / 192 / 384 without proj dropout: row-image kernel, natural-order image of wmlp (it follows the paired one)
+    if (mivp_tok_rows_supported(d) && !d->proj_drop_thr)
+        return mivp_tok_wide_proj_mlp_fwd(d, o, x, tok_src, tok_dst, wproj, bproj, ln_w, ln_b,
+                                          (const bf16_t*)wmlp + mivp_tok_natural_offset(d->C), bmlp, t1, y, st);
 #define LAUNCH_PM(K) hipLaunchKernelGGL((k_swin_proj_mlp_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)o, \
                                          (const bf16_t*)x, tok_src, tok_dst, (const bf16_t*)wproj, bproj, ln_w, ln_b,   \
                                          (const bf16_t*)wmlp, bmlp, (bf16_t*)t1, (bf16_t*)y)

@@ -2,19 +2,19 @@
 // Same operators as k_swin_qkv_fwd / k_swin_proj_mlp_fwd (swin_fwd.hip) and k_swin_proj_mlp_bwd / k_swin_qkv_bwd
 // (swin_bwd.hip) -- reference swin_transformer/swin_block.py:145-255 and its autograd -- in another work split.
 //
-// Why: the one-wave-per-16-tokens form gives the deep stages a few hundred workgroups whose single wave per SIMD walks
-// EVERY column tile (C = 192: 3100 VALU instructions and ~30 dependent load round trips per wave, 296 VGPRs -> one
-// workgroup per CU, two rounds; r02 PMC: 47 us for 2.5 GFLOP).  With so few waves nothing overlaps, so the kernel time is
-// (instructions + round trips) PER WAVE.  Here a workgroup owns 32 tokens per token group and its waves split the output
-// COLUMNS:
-//   * NCG column groups x NTG token groups = 4 waves (CT % 4 == 0: 4 x 1, 32 tokens; otherwise 2 x 2, 64 tokens);
-//     wave (cg, tg) computes column tiles cg, cg + NCG, ... for the two 16-token tiles of token group tg, so every weight
-//     fragment (straight from L2, no slab barriers) feeds two MFMAs;
-//   * everything that is per TOKEN is done once per workgroup by 256 / rows threads per token row and shared through LDS:
-//     the gather of the GEMM's B operand (row image, ds_read_b128 fragments), LayerNorm statistics, source / destination
-//     voxels;
-//   * row reductions that span column groups (LayerNorm-backward sums, LayerNorm statistics of a GEMM output) meet in LDS
-//     in column-group order (fixed order: bit-reproducible);
+// Why (r02 counters, DESIGN.md "token kernels"): the one-wave-per-16-tokens form is bound by the texture-address unit --
+// TA_BUSY is ~80 % of the kernel time -- because every global access is made in the MFMA operand lane map (lane (r, g):
+// token row r, 16-byte chunk g), where ADJACENT LANES TOUCH DIFFERENT ROWS: a wave load costs one TA cycle per lane
+// instead of one per 64 bytes.  At the deep stages it also leaves a few hundred single-wave-per-SIMD workgroups, each
+// walking every column tile behind ~30 dependent load round trips.  Here:
+//   * global memory is only touched in ROW-CONTIGUOUS patterns: TPR adjacent lanes per token row read / write 16-byte
+//     pieces of it; the head-major q / k / v tensors are touched as the contiguous [32 tokens][head_dim] chunk each
+//     (tensor, head) has per 32-token granule (windows hold a multiple of 32 slots);
+//   * the MFMA lane map only ever meets LDS: row images [rows][K] (+16 B per row: conflict-free ds_read_b128 fragments);
+//   * a workgroup owns 32 tokens per token group and its four waves split the output COLUMNS (NCG column groups x NTG
+//     token groups; CT % 4 == 0: 4 x 1, otherwise 2 x 2), so a weight fragment (fragment image: one coalesced 1 KB load)
+//     feeds two MFMAs and per-token work (LayerNorm statistics, gathers) is done once per workgroup;
+//   * row reductions across column groups meet in LDS in column-group order (bit-reproducible);
 //   * every global load is unconditional (common.hpp "Branch-free loads").
 // The launchers at the bottom are called by the C entries of swin_fwd.hip / swin_bwd.hip when mivp_tok_wide_supported().
 #include "common.hpp"
@@ -25,19 +25,23 @@ namespace {
 template <int CT>
 struct WideGeom {
     static constexpr int C = 16 * CT;
-    static constexpr int NCG = (CT % 4 == 0) ? 4 : 2;           // column groups
-    static constexpr int NTG = 4 / NCG;                          // token groups
-    static constexpr int NCT = CT / NCG;                         // column tiles per wave
+    static constexpr int KP = (C + 31) / 32 * 32;                // row images pad K to whole k-steps (C = 48: zero columns 48..63)
+    static constexpr int KS = KP / 32;
+    static constexpr int NCG = (CT % 4 == 0) ? 4 : (CT % 2 == 0 ? 2 : 1);     // column groups
+    static constexpr int NTG = 4 / NCG;                          // token groups (32-token granules per workgroup)
+    static constexpr int NCT = CT / NCG;                         // column tiles of a [.][C] output per wave
     static constexpr int ROWS = 32 * NTG;                        // token rows per workgroup
-    static constexpr int TPR = 256 / ROWS;                       // threads per token row in the per-token phases
-    static_assert(CT % NCG == 0, "column tiles must split evenly");
+    static constexpr int TPR = 256 / ROWS;                       // adjacent lanes per token row in the row phases
+    static constexpr int XPT = C / 8 / TPR;                      // 16-byte pieces of a [C] row per lane
+    static_assert(CT % NCG == 0 && (C / 8) % TPR == 0, "even splits");
 };
 
-// LDS row image of a GEMM B operand: [rows][K] bf16, +16 B per row (the 16 rows of a fragment read then cover all banks)
+// LDS row image: [rows][K] bf16, +16 B per row (the 16 rows of a fragment read then cover all banks)
 template <int K>
 struct RowImg {
     static constexpr int ROWB = 2 * K + 16;
     static MIVP_DEV bf16x8 frag(const char* img, int row, int k0) { return *reinterpret_cast<const bf16x8*>(img + row * ROWB + 2 * k0); }
+    static MIVP_DEV bf16x4 get4(const char* img, int row, int k0) { return *reinterpret_cast<const bf16x4*>(img + row * ROWB + 2 * k0); }
     static MIVP_DEV void put4(char* img, int row, int k0, bf16x4 v) { *reinterpret_cast<bf16x4*>(img + row * ROWB + 2 * k0) = v; }
     static MIVP_DEV void put8(char* img, int row, int k0, bf16x8 v) { *reinterpret_cast<bf16x8*>(img + row * ROWB + 2 * k0) = v; }
 };
@@ -56,81 +60,103 @@ MIVP_DEV RowTok row_token(const MivpSwinDesc& d, long t) {      // a dead row de
     ti.b = bpu / (unsigned)d.P;
     return ti;
 }
-// sum over the TPR consecutive lanes that share a token row
 template <int TPR>
-MIVP_DEV float row_sum(float v) {
+MIVP_DEV float row_sum(float v) {                                // sum over the TPR adjacent lanes of a token row
 #pragma unroll
     for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o);
     return v;
 }
+MIVP_DEV void to_f32(bf16x8 v, float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = (float)v[e];
+}
 
-// ---------------------------------------------------------------------------------------------
-// QKV + LayerNorm + gather backward:  (dq, dk, dv, dt1) -> dx        [k_swin_qkv_bwd, swin_bwd.hip]
-// ---------------------------------------------------------------------------------------------
-template <int CT>
-__global__ __launch_bounds__(256, 3) void k_qkv_bwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
-                                                         const bf16_t* __restrict__ dv, const bf16_t* __restrict__ x,
-                                                         const int* __restrict__ tok_src, const float* __restrict__ ln_w,
-                                                         const bf16_t* __restrict__ wqkv_t, const bf16_t* __restrict__ d_t1,
-                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out) {
-    using G = WideGeom<CT>;
-    constexpr int C = G::C, K3 = 3 * C, KS3 = K3 / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, NCT = G::NCT;
-    using BI = RowImg<K3>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Bimg = smem;                                                   // [ROWS][3C] = dq * scale | dk | dv of the token
-    float* stat = reinterpret_cast<float*>(Bimg + ROWS * BI::ROWB);      // [ROWS][2] mean, rstd of x
-    float* red = stat + 2 * ROWS;                                        // [ROWS][NCG][2] partial s1, s2
-    long* xbase = reinterpret_cast<long*>(red + 2 * ROWS * NCG);         // [ROWS] element offset of the x / dx row, -1: none
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int hd = C / d.heads;
-    const long row0 = (long)blockIdx.x * ROWS;
-
-    // ---- gradient pieces -> Bimg.  Lanes run along TOKENS for a fixed (q|k|v, head, 4-column piece): the head-major
-    //      layout keeps a window's consecutive tokens hd elements apart, so a wave-load touches ~7 lines per piece instead
-    //      of one line per 2-3 lanes (the texture-address unit takes about one cycle per line: r02 TA_BUSY counters) ----
-    {
-        const int row = tid % ROWS, pg = tid / ROWS;
-        constexpr int NPG = 256 / ROWS;                                   // piece groups (lanes sharing a token: none)
-        const RowTok ti = row_token(d, row0 + row);
-        const FastDiv by_hd(hd);
-        const long to_dk = dk - dq, to_dv = dv - dq;
-        const long row_qkv = (ti.bp * d.heads * d.Nqp + ti.slot) * (long)hd;
-        constexpr int PPT = (K3 / 4) / NPG;
-        bf16x4 pc[PPT];
+// Head-major q | k | v pieces of this workgroup's granules.  Per 32-token granule and (tensor, head) the tensor
+// [B*P*heads][Nqp][hd] holds one contiguous chunk of 32 * hd elements (Nqp % 32 == 0: a granule never leaves its window).
+// Piece P (8 bytes) of a granule: chunk = P / (8 hd), q = P % (8 hd) the piece within the chunk (token q / hd4, columns
+// 4 (q % hd4)): consecutive P are consecutive addresses.
+// visit(i, element offset within the tensor, tensor 0..2, image row, image column, live)
+template <int C, int NTG>
+struct HeadMajor {
+    long gbase[NTG];                                              // element offset of (granule, head 0) in a q / k / v tensor
+    bool glive[NTG];
+    int hd, hd4, heads;
+    long head_stride;
+    FastDiv by_chunk, by_hd4, by_heads;
+    static constexpr int PER_GRAN = 24 * C;                       // 3 tensors x 32 tokens x C / 4 pieces
+    static constexpr int PPT = PER_GRAN * NTG / 256;              // pieces per thread
+    MIVP_DEV HeadMajor(const MivpSwinDesc& d, long row0)
+        : hd(C / d.heads), hd4(C / d.heads / 4), heads(d.heads), head_stride((long)d.Nqp * (C / d.heads)),
+          by_chunk(8 * (C / d.heads)), by_hd4(C / d.heads / 4), by_heads(d.heads) {
+        const long T = (long)d.B * d.P * d.Nqp;
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int n0 = 4 * (pg + NPG * i);
-            const int which = n0 / C, cc = n0 - which * C, head = by_hd.div(cc), j0 = cc - head * hd;
-            const long base = sel(which == 0, 0L, sel(which == 1, to_dk, to_dv));
-            pc[i] = ld4(dq + base + row_qkv + (long)head * d.Nqp * hd + j0);
-        }
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int n0 = 4 * (pg + NPG * i);
-            bf16x4 val = keep_if(pc[i], ti.live);
-            const float sc = sel(n0 < C, d.q_scale, 1.0f);                // the q part carries the attention scale
-#pragma unroll
-            for (int j = 0; j < 4; ++j) val[j] = (bf16_t)((float)val[j] * sc);
-            BI::put4(Bimg, row, n0, val);
+        for (int gi = 0; gi < NTG; ++gi) {                        // the only full divisions: once per granule, not per piece
+            const long t0 = row0 + 32 * gi;
+            glive[gi] = t0 < T;
+            const unsigned tu = glive[gi] ? (unsigned)t0 : 0u;
+            const unsigned bp = tu / (unsigned)d.Nqp, slot0 = tu - bp * (unsigned)d.Nqp;
+            gbase[gi] = ((long)bp * heads * d.Nqp + slot0) * hd;
         }
     }
-    // ---- LayerNorm statistics of x: TPR adjacent lanes per token row read it in contiguous 16-byte pieces ----
-    {
+    // visit(i, element offset within the tensor, tensor 0..2, image row, image column, live) for this thread's pieces
+    template <class F>
+    MIVP_DEV void each(int tid, F&& visit) const {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int P = tid + 256 * i;
+            const int gran = P / PER_GRAN, pg = P - gran * PER_GRAN;
+            const int chunk = by_chunk.div(pg), q = pg - chunk * 8 * hd;
+            const int tensor = by_heads.div(chunk), head = chunk - tensor * heads;
+            const int tok = by_hd4.div(q), piece = q - tok * hd4;
+            long base = gbase[0];
+            bool live = glive[0];
+#pragma unroll
+            for (int gi = 1; gi < NTG; ++gi) { base = sel(gran == gi, gbase[gi], base); live = gran == gi ? glive[gi] : live; }
+            visit(i, base + head * head_stride + 4 * q, tensor, 32 * gran + tok, tensor * C + head * hd + 4 * piece, live);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// gather + LayerNorm + QKV                                             [k_swin_qkv_fwd, swin_fwd.hip]
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_fwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         const bf16_t* __restrict__ wqkv, bf16_t* __restrict__ q,
+                                                         bf16_t* __restrict__ k, bf16_t* __restrict__ v) {
+    using G = WideGeom<CT>;
+    constexpr int C = G::C, KS = C / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, XPT = G::XPT, NT3 = 3 * G::NCT;
+    using XI = RowImg<C>;
+    using OI = RowImg<3 * C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ximg = smem;                                           // [ROWS][C]  LayerNorm output (the GEMM's B operand)
+    char* Oimg = Ximg + ROWS * XI::ROWB;                         // [ROWS][3C] q * scale | k * log2 e | v
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * ROWS;
+    {   // ---- rows: gather, LayerNorm ----
         const int row = tid / TPR, sub = tid % TPR;
         const RowTok ti = row_token(d, row0 + row);
         const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
-        constexpr int XPT = C / TPR / 8;                                  // 16-byte pieces of the x row per thread
         const long xoff = (ti.b * d.vol_in + max(src, 0)) * (long)C;
         bf16x8 xr[XPT];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) xr[i] = ld8(x + xoff + 8 * (sub + TPR * i));
+        f32x4 w4[XPT][2], b4[XPT][2];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                w4[i][h] = *reinterpret_cast<const f32x4*>(ln_w + 8 * (sub + TPR * i) + 4 * h);
+                b4[i][h] = *reinterpret_cast<const f32x4*>(ln_b + 8 * (sub + TPR * i) + 4 * h);
+            }
         float xs[XPT][8], sum = 0.f;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const bf16x8 raw = keep_if(xr[i], src >= 0);
+            to_f32(keep_if(xr[i], src >= 0), xs[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { xs[i][e] = (float)raw[e]; sum += xs[i][e]; }
+            for (int e = 0; e < 8; ++e) sum += xs[i][e];
         }
         const float mean = row_sum<TPR>(sum) / (float)C;
         float var = 0.f;
@@ -139,33 +165,397 @@ __global__ __launch_bounds__(256, 3) void k_qkv_bwd_wide(MivpSwinDesc d, const b
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float dvv = xs[i][e] - mean; var += dvv * dvv; }
         const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            bf16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((xs[i][e] - mean) * rstd * w4[i][e >> 2][e & 3] + b4[i][e >> 2][e & 3]);
+            XI::put8(Ximg, row, 8 * (sub + TPR * i), keep_if(y, src >= -1));      // -1: a zero-pad token still goes through LN (-> beta)
+        }
+    }
+    __syncthreads();
+    {   // ---- GEMM: this wave's column tiles of the 3C outputs, two token tiles ----
+        const int cg = wave % NCG, tg = wave / NCG;
+        const int R0 = tg * 32 + r, R1 = R0 + 16;
+        bf16x8 b0[KS], b1[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { b0[s] = XI::frag(Ximg, R0, 32 * s + 8 * g); b1[s] = XI::frag(Ximg, R1, 32 * s + 8 * g); }
+#pragma unroll
+        for (int j = 0; j < NT3; ++j) {
+            const int nt = cg + NCG * j;
+            f32x4 a0 = fzero4(), a1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = wfrag(wqkv, KS, nt, s, lane);
+                a0 = mfma16(a, b0[s], a0);
+                a1 = mfma16(a, b1[s], a1);
+            }
+            const int n0 = 16 * nt + 4 * g;
+            const float sc = sel(n0 < C, d.q_scale, sel(n0 < 2 * C, MIVP_LOG2E, 1.0f));      // K carries log2(e): common.hpp
+            OI::put4(Oimg, R0, n0, pack4(a0 * sc));
+            OI::put4(Oimg, R1, n0, pack4(a1 * sc));
+        }
+    }
+    __syncthreads();
+    // ---- q | k | v: contiguous head-major chunks ----
+    const long to_k = k - q, to_v = v - q;
+    const HeadMajor<C, G::NTG> hm(d, row0);
+    hm.each(tid, [&](int, long off, int tensor, int irow, int icol, bool live) {
+        if (live) st4(q + sel(tensor == 0, 0L, sel(tensor == 1, to_k, to_v)) + off, OI::get4(Oimg, irow, icol));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// proj + residual -> LayerNorm -> Linear + residual -> scatter          [k_swin_proj_mlp_fwd, swin_fwd.hip]
+// (no proj dropout here: the launcher leaves those calls to the 16-token kernel)
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ o, const bf16_t* __restrict__ x,
+                                                              const int* __restrict__ tok_src, const int* __restrict__ tok_dst,
+                                                              const bf16_t* __restrict__ wproj, const float* __restrict__ bproj,
+                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                              const bf16_t* __restrict__ wmlp, const float* __restrict__ bmlp,
+                                                              bf16_t* __restrict__ t1_out, bf16_t* __restrict__ y) {
+    using G = WideGeom<CT>;
+    constexpr int C = G::C, KS = G::KS, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, NCT = G::NCT, XPT = G::XPT;
+    using RI = RowImg<G::KP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Aimg = smem;                                           // [ROWS][C]  o rows, later LN(t1) rows: the GEMMs' B operands
+    char* Ximg = Aimg + ROWS * RI::ROWB;                         // [ROWS][C]  shortcut rows, then t1 rows, then the output rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const int row = tid / TPR, sub = tid % TPR;                  // the row phases' lane map
+    const RowTok ti = row_token(d, row0 + row);
+    const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
+    const int dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
+    {   // ---- rows in: o, shortcut ----
+        const long xoff = (ti.b * d.vol_in + max(src, 0)) * (long)C;
+        bf16x8 orow[XPT], xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            orow[i] = ld8(o + ti.tt * (long)C + 8 * (sub + TPR * i));
+            xr[i] = ld8(x + xoff + 8 * (sub + TPR * i));
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            RI::put8(Aimg, row, 8 * (sub + TPR * i), keep_if(orow[i], ti.live));
+            RI::put8(Ximg, row, 8 * (sub + TPR * i), keep_if(xr[i], src >= 0));
+        }
+        if (G::KP != C && sub == 0)
+            for (int c = C; c < G::KP; c += 8) RI::put8(Aimg, row, c, zero8());          // the k-step padding of the B operand
+    }
+    __syncthreads();
+    const int cg = wave % NCG, tg = wave / NCG;
+    const int R0 = tg * 32 + r, R1 = R0 + 16;
+    f32x4 t1[NCT][2];
+    {   // ---- GEMM 1: t1 = o Wproj^T + b + shortcut (kept as bf16 values) ----
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const int nt = cg + NCG * j, n0 = 16 * nt + 4 * g;
+            const f32x4 bp4 = *reinterpret_cast<const f32x4*>(bproj + n0);
+            f32x4 a0 = fzero4(), a1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = wfrag(wproj, KS, nt, s, lane);
+                a0 = mfma16(a, RI::frag(Aimg, R0, 32 * s + 8 * g), a0);
+                a1 = mfma16(a, RI::frag(Aimg, R1, 32 * s + 8 * g), a1);
+            }
+            const bf16x4 s0 = RI::get4(Ximg, R0, n0), s1 = RI::get4(Ximg, R1, n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = (float)(bf16_t)(a0[e] + bp4[e] + (float)s0[e]);
+                a1[e] = (float)(bf16_t)(a1[e] + bp4[e] + (float)s1[e]);
+            }
+            t1[j][0] = a0;
+            t1[j][1] = a1;
+            RI::put4(Ximg, R0, n0, pack4(a0));                  // in place: this lane just read these eight bytes
+            RI::put4(Ximg, R1, n0, pack4(a1));
+        }
+    }
+    __syncthreads();
+    {   // ---- rows: t1 out, LayerNorm(t1) -> Aimg ----
+        float ts[XPT][8], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const bf16x8 raw = RI::frag(Ximg, row, 8 * (sub + TPR * i));
+            if (t1_out && ti.live) st8(t1_out + ti.tt * (long)C + 8 * (sub + TPR * i), raw);
+            to_f32(raw, ts[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += ts[i][e];
+        }
+        const float mean = row_sum<TPR>(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dvv = ts[i][e] - mean; var += dvv * dvv; }
+        const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = 8 * (sub + TPR * i);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ln_w + c), w1 = *reinterpret_cast<const f32x4*>(ln_w + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_b + c), b1 = *reinterpret_cast<const f32x4*>(ln_b + c + 4);
+            bf16x8 yy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yy[e] = (bf16_t)((ts[i][e] - mean) * rstd * w0[e] + b0[e]);
+                yy[4 + e] = (bf16_t)((ts[i][4 + e] - mean) * rstd * w1[e] + b1[e]);
+            }
+            RI::put8(Aimg, row, c, yy);
+        }
+    }
+    __syncthreads();
+    {   // ---- GEMM 2: t2 = t1 + LN(t1) Wmlp^T + b ----
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const int nt = cg + NCG * j, n0 = 16 * nt + 4 * g;
+            const f32x4 bm4 = *reinterpret_cast<const f32x4*>(bmlp + n0);
+            f32x4 a0 = fzero4(), a1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = wfrag(wmlp, KS, nt, s, lane);
+                a0 = mfma16(a, RI::frag(Aimg, R0, 32 * s + 8 * g), a0);
+                a1 = mfma16(a, RI::frag(Aimg, R1, 32 * s + 8 * g), a1);
+            }
+            RI::put4(Ximg, R0, n0, pack4(a0 + t1[j][0] + bm4));
+            RI::put4(Ximg, R1, n0, pack4(a1 + t1[j][1] + bm4));
+        }
+    }
+    __syncthreads();
+    if (dst >= 0) {                                              // ---- rows out: scatter ----
+        const long yoff = (ti.b * d.vol_out + dst) * (long)C;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) st8(y + yoff + 8 * (sub + TPR * i), RI::frag(Ximg, row, 8 * (sub + TPR * i)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// proj + MLP backward:  dy -> (dO, dt1)                                 [k_swin_proj_mlp_bwd, swin_bwd.hip]
+// (no proj dropout, no weight-gradient outputs here: the launcher leaves those calls to the 16-token kernel)
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, 3) void k_proj_mlp_bwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ dy, const int* __restrict__ tok_dst,
+                                                              const bf16_t* __restrict__ t1, const float* __restrict__ ln_w,
+                                                              const bf16_t* __restrict__ wmlp_t, const bf16_t* __restrict__ wproj_t,
+                                                              bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1) {
+    using G = WideGeom<CT>;
+    constexpr int C = G::C, KS = G::KS, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, NCT = G::NCT, XPT = G::XPT;
+    using RI = RowImg<G::KP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Dimg = smem;                                           // [ROWS][C]  dy rows (B of GEMM A), later the dO rows
+    char* Timg = Dimg + ROWS * RI::ROWB;                         // [ROWS][C]  t1 rows, then dt1 rows (B of GEMM B)
+    float* stat = reinterpret_cast<float*>(Timg + ROWS * RI::ROWB);      // [ROWS][2] mean, rstd of t1
+    float* red = stat + 2 * ROWS;                                // [ROWS][NCG][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const int row = tid / TPR, sub = tid % TPR;
+    const RowTok ti = row_token(d, row0 + row);
+    {   // ---- rows in: dy (gathered), t1 + its LayerNorm statistics ----
+        const int dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
+        const long yoff = (ti.b * d.vol_out + max(dst, 0)) * (long)C;
+        bf16x8 dr[XPT], tr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            dr[i] = ld8(dy + yoff + 8 * (sub + TPR * i));
+            tr[i] = ld8(t1 + ti.tt * (long)C + 8 * (sub + TPR * i));
+        }
+        float ts[XPT][8], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const bf16x8 tv = keep_if(tr[i], ti.live);
+            RI::put8(Dimg, row, 8 * (sub + TPR * i), keep_if(dr[i], dst >= 0));
+            RI::put8(Timg, row, 8 * (sub + TPR * i), tv);
+            to_f32(tv, ts[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += ts[i][e];
+        }
+        const float mean = row_sum<TPR>(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dvv = ts[i][e] - mean; var += dvv * dvv; }
+        const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
         if (sub == 0) {
             stat[2 * row] = mean;
             stat[2 * row + 1] = rstd;
-            xbase[row] = src >= 0 ? xoff : -1L;
+            for (int c = C; c < G::KP; c += 8) { RI::put8(Dimg, row, c, zero8()); RI::put8(Timg, row, c, zero8()); }     // k-step padding
         }
+    }
+    __syncthreads();
+    const int cg = wave % NCG, tg = wave / NCG;
+    const int R0 = tg * 32 + r, R1 = R0 + 16;
+    {   // ---- GEMM A: dh = dy Wmlp, LayerNorm backward, dt1 = dy + ... ----
+        f32x4 dh[NCT][2], xh[NCT][2];
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        const float mean0 = stat[2 * R0], rstd0 = stat[2 * R0 + 1], mean1 = stat[2 * R1], rstd1 = stat[2 * R1 + 1];
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const int nt = cg + NCG * j, n0 = 16 * nt + 4 * g;
+            const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + n0);
+            f32x4 a0 = fzero4(), a1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = wfrag(wmlp_t, KS, nt, s, lane);
+                a0 = mfma16(a, RI::frag(Dimg, R0, 32 * s + 8 * g), a0);
+                a1 = mfma16(a, RI::frag(Dimg, R1, 32 * s + 8 * g), a1);
+            }
+            const bf16x4 t0 = RI::get4(Timg, R0, n0), t1v = RI::get4(Timg, R1, n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = a0[e] * lw[e], d1 = a1[e] * lw[e];
+                const float h0 = ((float)t0[e] - mean0) * rstd0, h1 = ((float)t1v[e] - mean1) * rstd1;
+                a0[e] = d0; a1[e] = d1;
+                xh[j][0][e] = h0; xh[j][1][e] = h1;
+                s1[0] += d0; s2[0] += d0 * h0;
+                s1[1] += d1; s2[1] += d1 * h1;
+            }
+            dh[j][0] = a0;
+            dh[j][1] = a1;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float a = col_sum(s1[u]), b = col_sum(s2[u]);
+            if (g == 0) { float* dstp = red + ((u ? R1 : R0) * NCG + cg) * 2; dstp[0] = a; dstp[1] = b; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int R = u ? R1 : R0;
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCG; ++c) { m1 += red[(R * NCG + c) * 2]; m2 += red[(R * NCG + c) * 2 + 1]; }
+            m1 /= (float)C;
+            m2 /= (float)C;
+            const float rstd = u ? rstd1 : rstd0;
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) {
+                const int n0 = 16 * (cg + NCG * j) + 4 * g;
+                const bf16x4 dyv = RI::get4(Dimg, R, n0);
+                f32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = (float)dyv[e] + rstd * (dh[j][u][e] - m1 - xh[j][u][e] * m2);
+                RI::put4(Timg, R, n0, pack4(out));              // in place: this lane read these eight bytes of t1 above
+            }
+        }
+    }
+    __syncthreads();
+    // ---- rows out: dt1 (the residual branch) ----
+    if (ti.live) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) st8(d_t1 + ti.tt * (long)C + 8 * (sub + TPR * i), RI::frag(Timg, row, 8 * (sub + TPR * i)));
+    }
+    {   // ---- GEMM B: dO = dt1 Wproj ----
+        f32x4 acc[NCT][2];
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const int nt = cg + NCG * j;
+            f32x4 a0 = fzero4(), a1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = wfrag(wproj_t, KS, nt, s, lane);
+                a0 = mfma16(a, RI::frag(Timg, R0, 32 * s + 8 * g), a0);
+                a1 = mfma16(a, RI::frag(Timg, R1, 32 * s + 8 * g), a1);
+            }
+            acc[j][0] = a0;
+            acc[j][1] = a1;
+        }
+        // Dimg was last read (dy) before the barrier above: free for the dO rows
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const int n0 = 16 * (cg + NCG * j) + 4 * g;
+            RI::put4(Dimg, R0, n0, pack4(acc[j][0]));
+            RI::put4(Dimg, R1, n0, pack4(acc[j][1]));
+        }
+    }
+    __syncthreads();
+    if (ti.live) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) st8(d_o + ti.tt * (long)C + 8 * (sub + TPR * i), RI::frag(Dimg, row, 8 * (sub + TPR * i)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QKV + LayerNorm + gather backward:  (dq, dk, dv, dt1) -> dx           [k_swin_qkv_bwd, swin_bwd.hip]
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_bwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
+                                                         const bf16_t* __restrict__ dv, const bf16_t* __restrict__ x,
+                                                         const int* __restrict__ tok_src, const float* __restrict__ ln_w,
+                                                         const bf16_t* __restrict__ wqkv_t, const bf16_t* __restrict__ d_t1,
+                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out) {
+    using G = WideGeom<CT>;
+    constexpr int C = G::C, K3 = 3 * C, KS3 = K3 / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, NCT = G::NCT, XPT = G::XPT;
+    using BI = RowImg<K3>;
+    using RI = RowImg<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Bimg = smem;                                                   // [ROWS][3C] = dq * scale | dk | dv of the token
+    char* Ximg = Bimg + ROWS * BI::ROWB;                                 // [ROWS][C]  x rows, then the dx rows
+    float* stat = reinterpret_cast<float*>(Ximg + ROWS * RI::ROWB);      // [ROWS][2] mean, rstd of x
+    float* red = stat + 2 * ROWS;                                        // [ROWS][NCG][2] partial s1, s2
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const int row = tid / TPR, sub = tid % TPR;
+    const RowTok ti = row_token(d, row0 + row);
+    const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
+    const long xoff = (ti.b * d.vol_in + max(src, 0)) * (long)C;
+
+    // ---- head-major gradient chunks -> Bimg (loads first, the q part scaled on the way) ----
+    {
+        const HeadMajor<C, G::NTG> hm(d, row0);
+        const long to_dk = dk - dq, to_dv = dv - dq;
+        bf16x4 pc[HeadMajor<C, G::NTG>::PPT];
+        hm.each(tid, [&](int i, long off, int tensor, int, int, bool) {
+            pc[i] = ld4(dq + sel(tensor == 0, 0L, sel(tensor == 1, to_dk, to_dv)) + off);
+        });
+        // rows: x (LayerNorm statistics + image)
+        bf16x8 xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) xr[i] = ld8(x + xoff + 8 * (sub + TPR * i));
+        hm.each(tid, [&](int i, long, int tensor, int irow, int icol, bool live) {
+            bf16x4 val = keep_if(pc[i], live);
+            const float sc = sel(tensor == 0, d.q_scale, 1.0f);           // the q part carries the attention scale (x 1 is exact)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[j] = (bf16_t)((float)val[j] * sc);
+            BI::put4(Bimg, irow, icol, val);
+        });
+        float xs[XPT][8], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const bf16x8 xv = keep_if(xr[i], src >= 0);
+            RI::put8(Ximg, row, 8 * (sub + TPR * i), xv);
+            to_f32(xv, xs[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += xs[i][e];
+        }
+        const float mean = row_sum<TPR>(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dvv = xs[i][e] - mean; var += dvv * dvv; }
+        const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
+        if (sub == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
     }
     __syncthreads();
 
     // ---- GEMM: dn[token][c] = sum_n B[token][n] * wqkv_t[c][n], this wave's column tiles, two token tiles ----
     const int cg = wave % NCG, tg = wave / NCG;
     const int R0 = tg * 32 + r, R1 = R0 + 16;                             // this lane's token rows of the two tiles
-    const long xb0 = xbase[R0], xb1 = xbase[R1];
-    const long tt0 = row0 + R0, tt1 = row0 + R1;
     const long T = (long)d.B * d.P * d.Nqp;
-    const bool live0 = tt0 < T, live1 = tt1 < T;
-    // operands of the LayerNorm backward, issued before the GEMM (they arrive while it runs)
-    bf16x4 xq[NCT][2], tq[NCT][2];
-    f32x4 lw[NCT];
+    // dt1 in the accumulator lane map, straight from global (an LDS image of it would cost the third workgroup per CU:
+    // the 704 workgroups of a 12 x 12 x 24-token stage then run as two rounds); issued before the GEMM
+    bf16x4 tq[NCT][2];
 #pragma unroll
-    for (int j = 0; j < NCT; ++j) {
-        const int c0 = 16 * (cg + NCG * j) + 4 * g;
-        xq[j][0] = ld4(x + max(xb0, 0L) + c0);
-        xq[j][1] = ld4(x + max(xb1, 0L) + c0);
-        tq[j][0] = ld4(d_t1 + sel(live0, tt0, 0L) * C + c0);
-        tq[j][1] = ld4(d_t1 + sel(live1, tt1, 0L) * C + c0);
-        lw[j] = *reinterpret_cast<const f32x4*>(ln_w + c0);
-    }
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long tt = row0 + (u ? R1 : R0);
+            tq[j][u] = ld4(d_t1 + sel(tt < T, tt, 0L) * C + 16 * (cg + NCG * j) + 4 * g);
+        }
     f32x4 acc[NCT][2];
 #pragma unroll
     for (int j = 0; j < NCT; ++j) {
@@ -187,14 +577,16 @@ __global__ __launch_bounds__(256, 3) void k_qkv_bwd_wide(MivpSwinDesc d, const b
 #pragma unroll
     for (int j = 0; j < NCT; ++j) {
         const int c0 = 16 * (cg + NCG * j) + 4 * g;
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + c0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (dn_out && (u ? live1 : live0)) st4(dn_out + (u ? tt1 : tt0) * C + c0, pack4(acc[j][u]));
-            const bf16x4 raw = keep_if(xq[j][u], (u ? xb1 : xb0) >= 0);
+            const int R = u ? R1 : R0;
+            if (dn_out && row0 + R < T) st4(dn_out + (row0 + R) * C + c0, pack4(acc[j][u]));      // (weight-gradient mode)
+            const bf16x4 raw = RI::get4(Ximg, R, c0);
             const float mean = u ? mean1 : mean0, rstd = u ? rstd1 : rstd0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float dxh = acc[j][u][e] * lw[j][e];
+                const float dxh = acc[j][u][e] * lw[e];
                 const float h = ((float)raw[e] - mean) * rstd;
                 acc[j][u][e] = dxh;
                 xh[j][u][e] = h;
@@ -206,11 +598,7 @@ __global__ __launch_bounds__(256, 3) void k_qkv_bwd_wide(MivpSwinDesc d, const b
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const float a = col_sum(s1[u]), b = col_sum(s2[u]);
-        if (g == 0) {
-            float* dst = red + ((u ? R1 : R0) * NCG + cg) * 2;
-            dst[0] = a;
-            dst[1] = b;
-        }
+        if (g == 0) { float* dstp = red + ((u ? R1 : R0) * NCG + cg) * 2; dstp[0] = a; dstp[1] = b; }
     }
     __syncthreads();
 #pragma unroll
@@ -221,54 +609,130 @@ __global__ __launch_bounds__(256, 3) void k_qkv_bwd_wide(MivpSwinDesc d, const b
         for (int c = 0; c < NCG; ++c) { m1 += red[(R * NCG + c) * 2]; m2 += red[(R * NCG + c) * 2 + 1]; }
         m1 /= (float)C;
         m2 /= (float)C;
-        const long xb = u ? xb1 : xb0;
         const float rstd = u ? rstd1 : rstd0;
-        if (xb < 0) continue;                                             // zero-pad / padding-slot tokens have no voxel
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
             const int c0 = 16 * (cg + NCG * j) + 4 * g;
             f32x4 out;
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[e] = (float)tq[j][u][e] + rstd * (acc[j][u][e] - m1 - xh[j][u][e] * m2);
-            st4(dx + xb + c0, pack4(out));
+            RI::put4(Ximg, R, c0, pack4(out));                  // in place: this lane read these eight bytes of x above
         }
+    }
+    __syncthreads();
+    if (src >= 0) {                                              // ---- rows out (zero-pad / padding-slot tokens have no voxel) ----
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) st8(dx + xoff + 8 * (sub + TPR * i), RI::frag(Ximg, row, 8 * (sub + TPR * i)));
     }
 }
 
-template <int CT>
-size_t qkv_bwd_wide_lds() {
+template <int CT> size_t lds_qkv_fwd() { using G = WideGeom<CT>; return (size_t)G::ROWS * (RowImg<G::C>::ROWB + RowImg<3 * G::C>::ROWB); }
+template <int CT> size_t lds_proj_mlp_fwd() { using G = WideGeom<CT>; return (size_t)G::ROWS * 2 * RowImg<G::KP>::ROWB; }
+template <int CT> size_t lds_proj_mlp_bwd() {
     using G = WideGeom<CT>;
-    return (size_t)G::ROWS * RowImg<3 * G::C>::ROWB + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float) + G::ROWS * sizeof(long);
+    return (size_t)G::ROWS * 2 * RowImg<G::KP>::ROWB + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float);
+}
+template <int CT> size_t lds_qkv_bwd() {
+    using G = WideGeom<CT>;
+    return (size_t)G::ROWS * (RowImg<3 * G::C>::ROWB + RowImg<G::C>::ROWB) + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float);
 }
 
 }  // namespace
 
+// C = 96 / 192 / 384, windows of a multiple of 32 slots (a 32-token granule then never leaves its window)
 int mivp_tok_wide_supported(const MivpSwinDesc* d) {
     const int hd = d->C / d->heads;
     if (!(d->C == 96 || d->C == 192 || d->C == 384)) return 0;
     static const bool off = getenv("MIVP_NO_WIDE_TOKEN_KERNELS") != nullptr;     // A/B switch for profiling and tests
     if (off) return 0;
-    return (hd % 4 == 0 && hd < 65536) ? 1 : 0;
+    return (hd % 4 == 0 && d->Nqp % 32 == 0 && 8 * hd < 65536 && 72 * d->C < 65536) ? 1 : 0;
+}
+// the proj / MLP pair in the same form also at C = 48 (one column group: a wave owns its 32 tokens' three column tiles)
+int mivp_tok_rows_supported(const MivpSwinDesc* d) {
+    if (mivp_tok_wide_supported(d)) return 1;
+    static const bool off = getenv("MIVP_NO_WIDE_TOKEN_KERNELS") != nullptr;
+    return (!off && d->C == 48) ? 1 : 0;
+}
+// element offset of the natural-order image behind the paired one (swin_ops.paired_and_natural)
+long mivp_tok_natural_offset(int C) { return (long)(C / 16) * ((C + 31) / 32) * 512; }
+
+#define ROWS_SWITCH(LAUNCH)                                                                  \
+    switch (d->C) {                                                                          \
+        case 48: LAUNCH(3); break;                                                           \
+        case 96: LAUNCH(6); break;                                                           \
+        case 192: LAUNCH(12); break;                                                         \
+        case 384: LAUNCH(24); break;                                                         \
+        default: mivp_set_error("tok_rows: C not in {48, 96, 192, 384}"); return MIVP_EUNSUPPORTED; \
+    }
+#define WIDE_SWITCH(LAUNCH)                                                                  \
+    switch (d->C) {                                                                          \
+        case 96: LAUNCH(6); break;                                                           \
+        case 192: LAUNCH(12); break;                                                         \
+        case 384: LAUNCH(24); break;                                                         \
+        default: mivp_set_error("tok_wide: C not in {96, 192, 384}"); return MIVP_EUNSUPPORTED; \
+    }
+#define WIDE_GRID(CTV) dim3((unsigned)((T + WideGeom<CTV>::ROWS - 1) / WideGeom<CTV>::ROWS))
+
+int mivp_tok_wide_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* tok_src, const float* ln_w, const float* ln_b,
+                          const void* wqkv, void* q, void* k, void* v, hipStream_t st) {
+    const long T = (long)d->B * d->P * d->Nqp;
+#define L_W(CTV)                                                                                                             \
+    do {                                                                                                                     \
+        const size_t lds = lds_qkv_fwd<CTV>();                                                                               \
+        MIVP_LDS_OPT_IN(k_qkv_fwd_wide<CTV>, lds);                                                                           \
+        hipLaunchKernelGGL((k_qkv_fwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)x, tok_src, ln_w,   \
+                           ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v);                                   \
+    } while (0)
+    WIDE_SWITCH(L_W)
+#undef L_W
+    return mivp_check_launch("swin_qkv_fwd(wide)");
+}
+
+int mivp_tok_wide_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x, const int32_t* tok_src, const int32_t* tok_dst,
+                               const void* wproj, const float* bproj, const float* ln_w, const float* ln_b, const void* wmlp,
+                               const float* bmlp, void* t1_out, void* y, hipStream_t st) {
+    const long T = (long)d->B * d->P * d->Nqp;
+#define L_W(CTV)                                                                                                              \
+    do {                                                                                                                      \
+        const size_t lds = lds_proj_mlp_fwd<CTV>();                                                                           \
+        MIVP_LDS_OPT_IN(k_proj_mlp_fwd_wide<CTV>, lds);                                                                       \
+        hipLaunchKernelGGL((k_proj_mlp_fwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)o,              \
+                           (const bf16_t*)x, tok_src, tok_dst, (const bf16_t*)wproj, bproj, ln_w, ln_b, (const bf16_t*)wmlp,  \
+                           bmlp, (bf16_t*)t1_out, (bf16_t*)y);                                                                \
+    } while (0)
+    ROWS_SWITCH(L_W)
+#undef L_W
+    return mivp_check_launch("swin_proj_mlp_fwd(wide)");
+}
+
+int mivp_tok_wide_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1, const float* ln_w,
+                               const void* wmlp_t, const void* wproj_t, void* d_o, void* d_t1, hipStream_t st) {
+    const long T = (long)d->B * d->P * d->Nqp;
+#define L_W(CTV)                                                                                                             \
+    do {                                                                                                                     \
+        const size_t lds = lds_proj_mlp_bwd<CTV>();                                                                          \
+        MIVP_LDS_OPT_IN(k_proj_mlp_bwd_wide<CTV>, lds);                                                                      \
+        hipLaunchKernelGGL((k_proj_mlp_bwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)dy, tok_dst,   \
+                           (const bf16_t*)t1, ln_w, (const bf16_t*)wmlp_t, (const bf16_t*)wproj_t, (bf16_t*)d_o,             \
+                           (bf16_t*)d_t1);                                                                                   \
+    } while (0)
+    ROWS_SWITCH(L_W)
+#undef L_W
+    return mivp_check_launch("swin_proj_mlp_bwd(wide)");
 }
 
 int mivp_tok_wide_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv, const void* x, const int32_t* tok_src,
                           const float* ln_w, const void* wqkv_t, const void* d_t1, void* dx, void* dn_out, hipStream_t st) {
     const long T = (long)d->B * d->P * d->Nqp;
-#define L_WQB(CTV)                                                                                                          \
-    do {                                                                                                                    \
-        const size_t lds = qkv_bwd_wide_lds<CTV>();                                                                         \
-        MIVP_LDS_OPT_IN(k_qkv_bwd_wide<CTV>, lds);                                                                          \
-        const unsigned grid = (unsigned)((T + WideGeom<CTV>::ROWS - 1) / WideGeom<CTV>::ROWS);                              \
-        hipLaunchKernelGGL((k_qkv_bwd_wide<CTV>), dim3(grid), dim3(256), lds, st, *d, (const bf16_t*)dq, (const bf16_t*)dk, \
-                           (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, (const bf16_t*)wqkv_t, (const bf16_t*)d_t1,  \
-                           (bf16_t*)dx, (bf16_t*)dn_out);                                                                   \
+#define L_W(CTV)                                                                                                             \
+    do {                                                                                                                     \
+        const size_t lds = lds_qkv_bwd<CTV>();                                                                               \
+        MIVP_LDS_OPT_IN(k_qkv_bwd_wide<CTV>, lds);                                                                           \
+        hipLaunchKernelGGL((k_qkv_bwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)dq, (const bf16_t*)dk, \
+                           (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, (const bf16_t*)wqkv_t, (const bf16_t*)d_t1,   \
+                           (bf16_t*)dx, (bf16_t*)dn_out);                                                                    \
     } while (0)
-    switch (d->C) {
-        case 96: L_WQB(6); break;
-        case 192: L_WQB(12); break;
-        case 384: L_WQB(24); break;
-        default: mivp_set_error("tok_wide: C not in {96, 192, 384}"); return MIVP_EUNSUPPORTED;
-    }
-#undef L_WQB
+    WIDE_SWITCH(L_W)
+#undef L_W
     return mivp_check_launch("swin_qkv_bwd(wide)");
 }

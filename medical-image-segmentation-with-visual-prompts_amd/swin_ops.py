@@ -64,6 +64,19 @@ def pack_weight_frags(wm: torch.Tensor, paired: bool = False, k_steps: int = 0) 
     return wp.view(Rp // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()      # [nt][r][s][g][e] -> [nt][s][g][r][e]
 
 
+WIDE_C = (48, 96, 192, 384)                              # csrc/swin_tok_wide.hip (proj / MLP pair)
+
+
+def paired_and_natural(wm: torch.Tensor) -> torch.Tensor:
+    """Image of the second GEMM's weight of the proj/MLP kernels: the paired form; for the wide stages followed by the
+    natural form (the column-split kernels feed that GEMM from an LDS row image, in natural k order; which kernel runs is
+    decided per call -- dropout and weight-gradient outputs stay with the 16-token kernel)."""
+    img = pack_weight_frags(wm, paired=True)
+    if wm.shape[0] in WIDE_C:
+        img = torch.cat([img.reshape(-1), pack_weight_frags(wm).reshape(-1)])
+    return img
+
+
 def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=False) -> SwinBlockWeights:
     f = lambda k: sd[prefix + k].detach().to(device=device, dtype=torch.float32).contiguous()
     scale = embed_dim ** -0.5
@@ -81,12 +94,12 @@ def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=
         bmlp=f("mlp.bias"), t_h=tabs[0], t_w=tabs[1], t_d=tabs[2], ts=ts)
     w.wqkv_f = pack_weight_frags(w.wqkv)
     w.wproj_f = pack_weight_frags(w.wproj)
-    w.wmlp_f = pack_weight_frags(w.wmlp, paired=True)
+    w.wmlp_f = paired_and_natural(w.wmlp)
     if need_bwd:
         ct = (w.wqkv.shape[1] + 15) // 16                # k_swin_qkv_bwd<CT> walks ceil(3 * 16 CT / 32) k-steps (C = 8: two)
         w.wqkv_t = pack_weight_frags(w.wqkv.t(), k_steps=(3 * 16 * ct + 31) // 32)
         w.wmlp_t = pack_weight_frags(w.wmlp.t())
-        w.wproj_t = pack_weight_frags(w.wproj.t(), paired=True)
+        w.wproj_t = paired_and_natural(w.wproj.t())
     return w
 
 
