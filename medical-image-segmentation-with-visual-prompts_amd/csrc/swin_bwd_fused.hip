@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
 // mivp_win_attn_bwd_dkv (which staged every query for four key tiles: 141 us -> see profiles/).
 // ---------------------------------------------------------------------------------------------
 template <int NW, bool DROP>
-__global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_prompt(
+__global__ __launch_bounds__(64 * NW, DROP ? 4 : 8) void k_win_attn_bwd_prompt(
     MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
     const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
     const float* __restrict__ lse, float* __restrict__ dkp_part, float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
@@ -433,7 +433,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_prompt(
     char* Oimg = Qimg + (size_t)nq * 64;
     float* lse_s = reinterpret_cast<float*>(Oimg + (size_t)nq * 32);
     float* del_s = lse_s + nq;
-    float* red = del_s + nq;                                  // [NW][2][256] + [NW][64] partial accumulators
+    // [NW][2][256] + [NW][64] partial accumulators: over the Q' image once the tile loop is done (a workgroup lives ~10 us
+    // behind its staging round trips: four workgroups per CU instead of two hide them)
+    float* red = reinterpret_cast<float*>(smem);
     const bf16_t* qb = q + bph * (long)Nqp * hd;
     const bf16_t* kpb = kp + (long)head * d.Npp * hd;
     const bf16_t* vpb = vp + (long)head * d.Npp * hd;
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_prompt(
         dvacc = mfma16k16(ot, pack4_pk(pv), dvacc);
     }
     // add the parts (fixed order), store this (window, head)'s partials
+    __syncthreads();                                          // every wave is done reading Qimg / Oimg
     float* mine = red + (size_t)wave * 576;
     *reinterpret_cast<f32x4*>(mine + r * 16 + 4 * g) = dkacc;
     *reinterpret_cast<f32x4*>(mine + 256 + r * 16 + 4 * g) = dvacc;
@@ -521,13 +524,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_prompt(
     }
 }
 
+static size_t prompt_lds_bytes(const MivpSwinDesc* d) {
+    const size_t images = (size_t)d->Nqp * 96, red = 8 * 576 * 4;                  // the partials reuse the images' space
+    return (images > red ? images : red) + 2 * (size_t)d->Nqp * 4;
+}
+
 extern "C" int mivp_win_attn_bwd_prompt_supported(const MivpSwinDesc* d) {
     if (!d || d->heads <= 0 || d->C % d->heads || d->Np <= 0) return 0;
     const int hd = d->C / d->heads, kp = d->Npp / 16;
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt) || dks != 1) return 0;
     if (hd > 16 || hd % 4 || d->augp < 4 || !(kp == 1 || kp == 2 || kp == 4 || kp == 8) || d->Nqp % 16) return 0;
-    const size_t lds = (size_t)d->Nqp * 96 + 2 * (size_t)d->Nqp * 4 + 8 * 576 * 4;
+    const size_t lds = prompt_lds_bytes(d);
     return lds <= 78 * 1024 ? 1 : 0;
 }
 
@@ -536,7 +544,7 @@ extern "C" int mivp_win_attn_bwd_prompt(const MivpSwinDesc* d, const void* q, co
                                         float* dvp_part, float* dtok_part, mivp_stream_t stream) {
     MIVP_REQUIRE(d && q && kp && vp && qa && ka && o && d_o && lse && dkp_part && dvp_part && dtok_part);
     if (!mivp_win_attn_bwd_prompt_supported(d)) { mivp_set_error("win_attn_bwd_prompt: shape outside the kernel's range"); return MIVP_EUNSUPPORTED; }
-    const size_t lds = (size_t)d->Nqp * 96 + 2 * (size_t)d->Nqp * 4 + 8 * 576 * 4;
+    const size_t lds = prompt_lds_bytes(d);
     constexpr int NW = 8;
     auto kern = d->attn_drop_thr ? k_win_attn_bwd_prompt<NW, true> : k_win_attn_bwd_prompt<NW, false>;
     MIVP_LDS_OPT_IN(kern, lds);
