@@ -76,8 +76,25 @@ typedef struct MivpSwinDesc {
     uint32_t proj_drop_thr;   float proj_drop_scale;   uint32_t proj_seed;
 } MivpSwinDesc;
 
+/* Weight fragment images (ABI 9).  The four token kernels below read their GEMM weights as MFMA-fragment-major images:
+ *   [ceil(rows / 16) row tiles][k_steps][64 lanes][8] bf16, zero padded; lane 16 g + r of (row tile nt, k-step s) holds
+ *   W[16 nt + r][32 s + 8 g .. + 8]  ("natural"), or W[..][32 s + 4 g .. + 4] | W[..][32 s + 16 + 4 g .. + 4] ("paired": the k
+ *   order of a GEMM whose B operand is the previous GEMM's accumulator tile pair).  A wave's A fragment is then one
+ *   contiguous 1 KB load.  k_steps = ceil(cols / 32), except wqkv_t: ceil(3 * 16 * ceil(C / 16) / 32).
+ *   mivp_pack_weight_frags builds one image from a row-major [rows][cols] bf16 matrix (out: ceil(rows/16) * k_steps * 512
+ *   elements).  Images per entry:
+ *     mivp_swin_qkv_fwd       wqkv    = natural image of [3C][C]
+ *     mivp_swin_proj_mlp_fwd  wproj   = natural image of [C][C];  wmlp = paired image of [C][C], and for C in {48, 96, 192,
+ *                                       384} the natural image directly behind it (the row-image kernels of those widths
+ *                                       feed the second GEMM from LDS in natural k order; dropout calls use the paired one)
+ *     mivp_swin_proj_mlp_bwd  wmlp_t  = natural image of Wmlp^T;  wproj_t = paired (+ natural, as above) image of Wproj^T
+ *     mivp_swin_qkv_bwd       wqkv_t  = natural image of Wqkv^T [C][3C]
+ *   (mivp_prompt_kv_fwd / _bwd keep the row-major wqkv.)                                                                  */
+int mivp_pack_weight_frags(const void* w, int32_t rows, int32_t cols, int32_t k_steps, int32_t paired, void* out,
+                           mivp_stream_t stream);
+
 /* gather + LayerNorm + q/k/v projections  (swin_block.py:205-214, window_attention.py:42-47)
- *   x [B, vol_in, C] bf16;  ln_w, ln_b [C] f32;  wqkv [3C][C] bf16 (to_q, to_k, to_v stacked)
+ *   x [B, vol_in, C] bf16;  ln_w, ln_b [C] f32;  wqkv = fragment image of [3C][C] (to_q, to_k, to_v stacked), see above
  *   q, k, v [B*P][heads][Nqp][hd] bf16 ; q is pre-multiplied by q_scale ; slots >= Nq are zero.
  *   k is stored multiplied by log2(e): the attention kernels keep logits in log2 units so that S = K'Q'^T feeds
  *   v_exp_f32 directly (the gradient entries below still take / return dk w.r.t. the un-scaled k).           */
@@ -120,7 +137,8 @@ int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const
 
 /* proj + residual, drop prompts, LayerNorm + Linear + residual, scatter + crop
  * (window_attention.py:60, swin_block.py:221-253)
- *   t1 [B*P][Nqp][C] bf16 (saved for backward, may be NULL) ; y [B, vol_out, C] bf16 */
+ *   t1 [B*P][Nqp][C] bf16 (saved for backward, may be NULL) ; y [B, vol_out, C] bf16
+ *   wproj, wmlp: weight fragment images (see "Weight fragment images" above) */
 int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x,
                            const int32_t* tok_src, const int32_t* tok_dst,
                            const void* wproj, const float* bproj, const float* ln_w, const float* ln_b,
@@ -128,7 +146,7 @@ int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x,
 
 /* ---- backward of the block: data gradients + prompt / token-bias gradients ---- */
 /* dy [B, vol_out, C] bf16 -> dO [B*P][Nqp][C] bf16 and dt1 [B*P][Nqp][C] bf16
- *   wmlp_t = mlp.weight^T, wproj_t = proj.weight^T  ([in][out] -> rows are input channels)
+ *   wmlp_t, wproj_t = fragment images of mlp.weight^T, proj.weight^T  ([in][out] -> rows are input channels)
  *   weight-gradient mode (both or neither, else NULL): dn_out [B*P][Nqp][C] bf16 = gradient w.r.t. the
  *   mlp_norm output, dyw [B*P][Nqp][C] bf16 = dy in window order (zero rows where the token was cropped) */
 int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, const int32_t* tok_dst, const void* t1,
@@ -190,7 +208,7 @@ int mivp_relbias_grad(const MivpSwinDesc* d, const float* dka /* [heads][Nkp][32
                       float* d_td, mivp_stream_t stream);
 
 /* dq,dk,dv -> (x W^T backward) -> LayerNorm backward -> + dt1 -> scatter to dx [B, vol_in, C] bf16
- *   wqkv_t [C][3C] bf16 = stacked weight transposed; q part is multiplied by q_scale inside
+ *   wqkv_t = fragment image of the stacked weight transposed [C][3C]; q part is multiplied by q_scale inside
  *   dn_out (NULL or [B*P][Nqp][C] bf16): gradient w.r.t. the attn_norm output (weight-gradient mode) */
 int mivp_swin_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk, const void* dv,
                       const void* x, const int32_t* tok_src, const float* ln_w, const float* ln_b,

@@ -637,7 +637,31 @@ template <int CT> size_t lds_qkv_bwd() {
     return (size_t)G::ROWS * (RowImg<3 * G::C>::ROWB + RowImg<G::C>::ROWB) + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float);
 }
 
+// w row-major [rows][cols] -> fragment image [rows/16 (up)][k_steps][64 lanes][8]
+__global__ __launch_bounds__(256) void k_pack_weight_frags(const bf16_t* __restrict__ w, int rows, int cols, int k_steps, int paired,
+                                                           bf16_t* __restrict__ out, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long frag = i >> 9;
+        const int s = (int)(frag % k_steps), nt = (int)(frag / k_steps);
+        const int r = lane & 15, g = lane >> 4;
+        const int row = 16 * nt + r;
+        const int col = 32 * s + (paired ? 16 * (e >> 2) + 4 * g + (e & 3) : 8 * g + e);
+        out[i] = (row < rows && col < cols) ? w[(long)row * cols + col] : (bf16_t)0.0f;
+    }
+}
+
 }  // namespace
+
+extern "C" int mivp_pack_weight_frags(const void* w, int32_t rows, int32_t cols, int32_t k_steps, int32_t paired, void* out,
+                                      mivp_stream_t stream) {
+    MIVP_REQUIRE(w && out && rows > 0 && cols > 0 && k_steps >= (cols + 31) / 32);
+    const long total = (long)((rows + 15) / 16) * k_steps * 512;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_pack_weight_frags, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, rows, cols, k_steps,
+                       paired, (bf16_t*)out, total);
+    return mivp_check_launch("pack_weight_frags");
+}
 
 // C = 96 / 192 / 384, windows of a multiple of 32 slots (a 32-token granule then never leaves its window)
 int mivp_tok_wide_supported(const MivpSwinDesc* d) {

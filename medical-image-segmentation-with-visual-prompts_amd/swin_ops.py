@@ -53,15 +53,12 @@ def pack_weight_frags(wm: torch.Tensor, paired: bool = False, k_steps: int = 0) 
     accumulator).  A wave's A fragment is then 1 KB contiguous: one fully coalesced load instead of 64 scattered 16-byte
     ones (the texture-address unit spends about a cycle per cache line touched -- DESIGN.md, r02 TA counters)."""
     R, K = wm.shape
-    Rp, Kp = (R + 15) // 16 * 16, max((K + 31) // 32, k_steps) * 32     # k_steps: the kernel's count when it exceeds ceil(K / 32)
-    if (Rp, Kp) != (R, K):
-        wp = torch.zeros((Rp, Kp), dtype=wm.dtype, device=wm.device)
-        wp[:R, :K] = wm
-    else:
-        wp = wm.contiguous()
-    if paired:                                           # [nt][r][s][half][g][e] -> [nt][s][g][r][half][e]
-        return wp.view(Rp // 16, 16, Kp // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()
-    return wp.view(Rp // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()      # [nt][r][s][g][e] -> [nt][s][g][r][e]
+    ks = max((K + 31) // 32, k_steps)                    # k_steps: the kernel's count when it exceeds ceil(K / 32)
+    src = wm.contiguous()
+    out = torch.empty(((R + 15) // 16, ks, 64, 8), dtype=BF16, device=wm.device)
+    L.call("mivp_pack_weight_frags", L.ptr(src), C.c_int32(R), C.c_int32(K), C.c_int32(ks), C.c_int32(1 if paired else 0),
+           L.ptr(out), L.stream())
+    return out
 
 
 WIDE_C = (48, 96, 192, 384)                              # csrc/swin_tok_wide.hip (proj / MLP pair)

@@ -500,3 +500,25 @@ def test_conv_transpose_k2s2(stride, cin, cout, dims):
     assert rel_l2(y.detach().float().cpu().permute(0, 4, 1, 2, 3), want.detach()) < 3e-3       # bf16 output rounding
     assert rel_l2(xc.grad.float().cpu().permute(0, 4, 1, 2, 3), xr.grad) < 3e-3
     assert rel_l2(conv.weight.grad.cpu(), dw_want) < 2e-3
+
+
+@pytest.mark.parametrize("rows,cols,k_steps,paired", [(48, 48, 0, False), (48, 48, 0, True), (144, 48, 0, False),
+                                                      (48, 144, 5, False), (8, 24, 2, False), (192, 576, 0, False)])
+def test_pack_weight_frags(rows, cols, k_steps, paired):
+    """mivp_pack_weight_frags against the layout formula of include/mivp.h ("Weight fragment images")."""
+    import mivp_amd
+    from mivp_amd import swin_ops
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(rows, cols, generator=gen).to(torch.bfloat16)
+    img = swin_ops.pack_weight_frags(w.to(DEV), paired=paired, k_steps=k_steps).cpu().float()
+    nt, ks = (rows + 15) // 16, max((cols + 31) // 32, k_steps)
+    assert img.shape == (nt, ks, 64, 8)
+    wp = torch.zeros(nt * 16, ks * 32)
+    wp[:rows, :cols] = w.float()
+    want = torch.empty(nt, ks, 64, 8)
+    for g in range(4):
+        for e in range(8):
+            col = (16 * (e >> 2) + 4 * g + (e & 3)) if paired else 8 * g + e
+            # lane = 16 g + r
+            want[:, :, 16 * g:16 * g + 16, e] = wp.view(nt, 16, ks, 32)[:, :, :, col].permute(0, 2, 1)
+    assert torch.equal(img, want)
