@@ -12,6 +12,8 @@ STAGES = {  # C, heads, dims (96^3 input), prompts
     "enc0": (48, 4, (48, 48, 48), 64), "enc1": (96, 8, (24, 24, 24), 64), "enc2": (192, 16, (12, 12, 24), 64),
     "dec0": (192, 4, (12, 12, 24), 0), "dec1": (96, 4, (24, 24, 24), 0), "dec2": (48, 4, (48, 48, 48), 0),
 }
+if os.environ.get("MIVP_TWO_PASS_ATTN_BWD"):          # A/B: the dq + dkv pair instead of the one-pass backward
+    swin_ops.USE_FUSED_ATTN_BWD = False
 stage = sys.argv[1] if len(sys.argv) > 1 else "enc0"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 shift = (3, 3, 3) if (len(sys.argv) > 3 and sys.argv[3] == "shift") else (0, 0, 0)
