@@ -92,6 +92,13 @@ typedef struct MivpSwinDesc {
  *   (mivp_prompt_kv_fwd / _bwd keep the row-major wqkv.)                                                                  */
 int mivp_pack_weight_frags(const void* w, int32_t rows, int32_t cols, int32_t k_steps, int32_t paired, void* out,
                            mivp_stream_t stream);
+/* Every image of one Swin block in one launch, from the f32 [C][C] masters of to_q, to_k, to_v, proj and mlp
+ * (swin_block.py:60-80).  Outputs bf16, any may be NULL: wqkv_rm [3C][C] row-major (for mivp_prompt_kv_fwd / _bwd),
+ * wqkv_f, wproj_f, wmlp_f, wqkv_t, wmlp_t, wproj_t exactly as the table above; with_natural != 0 appends the natural images
+ * behind the paired ones of wmlp_f / wproj_t (element offset ceil(C/16) * ceil(C/32) * 512).                            */
+int mivp_pack_block_weights(int32_t C, const float* wq, const float* wk, const float* wv, const float* wproj,
+                            const float* wmlp, int32_t with_natural, void* wqkv_rm, void* wqkv_f, void* wproj_f,
+                            void* wmlp_f, void* wqkv_t, void* wmlp_t, void* wproj_t, mivp_stream_t stream);
 
 /* gather + LayerNorm + q/k/v projections  (swin_block.py:205-214, window_attention.py:42-47)
  *   x [B, vol_in, C] bf16;  ln_w, ln_b [C] f32;  wqkv = fragment image of [3C][C] (to_q, to_k, to_v stacked), see above

@@ -651,7 +651,90 @@ __global__ __launch_bounds__(256) void k_pack_weight_frags(const bf16_t* __restr
     }
 }
 
+// All kernel-ready images of one Swin block's five weight matrices in ONE launch (a training step where every parameter
+// changes rebuilt them with ~25 launches per block: transposes, casts, concatenations, one pack per image).
+struct PackJob {
+    bf16_t* out;          // destination
+    long elems;           // number of output elements
+    int src;              // 0: [wq; wk; wv] stacked [3C][C], 1: wproj, 2: wmlp
+    int transposed;       // image of the transpose
+    int kind;             // 0: row-major bf16 copy, 1: natural fragment image, 2: paired fragment image
+    int rows, cols;       // of the (possibly transposed) matrix the image describes
+    int k_steps;
+};
+struct PackJobs { PackJob job[12]; int n; int C; const float* w[5]; };
+
+__global__ __launch_bounds__(256) void k_pack_block_weights(PackJobs jobs) {
+    const int C = jobs.C;
+    long total = 0;
+    for (int j = 0; j < jobs.n; ++j) total += jobs.job[j].elems;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long rest = i;
+        int j = 0;
+        while (rest >= jobs.job[j].elems) { rest -= jobs.job[j].elems; ++j; }
+        const PackJob& jb = jobs.job[j];
+        int row, col;
+        if (jb.kind == 0) {
+            row = (int)(rest / jb.cols);
+            col = (int)(rest - (long)row * jb.cols);
+        } else {
+            const int e = (int)(rest & 7), lane = (int)((rest >> 3) & 63);
+            const long frag = rest >> 9;
+            const int s = (int)(frag % jb.k_steps), nt = (int)(frag / jb.k_steps);
+            row = 16 * nt + (lane & 15);
+            const int g = lane >> 4;
+            col = 32 * s + (jb.kind == 2 ? 16 * (e >> 2) + 4 * g + (e & 3) : 8 * g + e);
+        }
+        float val = 0.f;
+        if (row < jb.rows && col < jb.cols) {
+            const int r0 = jb.transposed ? col : row, c0 = jb.transposed ? row : col;      // element of the untransposed matrix
+            const float* m = jb.src == 0 ? jobs.w[r0 / C] : jobs.w[2 + jb.src];
+            val = m[(long)(jb.src == 0 ? r0 % C : r0) * C + c0];
+        }
+        jb.out[rest] = (bf16_t)val;
+    }
+}
+
 }  // namespace
+
+/* wq, wk, wv, wproj, wmlp: f32 [C][C] row-major ([out][in]).  Outputs (bf16; any may be NULL = skipped):
+ *   wqkv_rm  [3C][C] row-major (prompt K/V kernels)      wqkv_f   natural image of [3C][C]
+ *   wproj_f  natural image                                wmlp_f   paired image (+ natural behind it when with_natural)
+ *   wqkv_t   natural image of [C][3C], k_steps = ceil(3 * 16 * ceil(C / 16) / 32)
+ *   wmlp_t   natural image of Wmlp^T                      wproj_t  paired (+ natural) image of Wproj^T               */
+extern "C" int mivp_pack_block_weights(int32_t C, const float* wq, const float* wk, const float* wv, const float* wproj,
+                                       const float* wmlp, int32_t with_natural, void* wqkv_rm, void* wqkv_f, void* wproj_f,
+                                       void* wmlp_f, void* wqkv_t, void* wmlp_t, void* wproj_t, mivp_stream_t stream) {
+    MIVP_REQUIRE(C > 0 && wq && wk && wv && wproj && wmlp);
+    PackJobs jobs;
+    jobs.n = 0;
+    jobs.C = C;
+    jobs.w[0] = wq; jobs.w[1] = wk; jobs.w[2] = wv; jobs.w[3] = wproj; jobs.w[4] = wmlp;
+    const int ct = (C + 15) / 16, ks = (C + 31) / 32, ks3 = (3 * 16 * ct + 31) / 32, ct3 = (3 * C + 15) / 16;
+    auto add = [&](void* out, int src, int transposed, int kind, int rows, int cols, int k_steps) {
+        if (!out) return;
+        PackJob& j = jobs.job[jobs.n++];
+        j.out = (bf16_t*)out; j.src = src; j.transposed = transposed; j.kind = kind; j.rows = rows; j.cols = cols; j.k_steps = k_steps;
+        j.elems = kind == 0 ? (long)rows * cols : (long)((rows + 15) / 16) * k_steps * 512;
+    };
+    const long img = (long)ct * ks * 512;
+    add(wqkv_rm, 0, 0, 0, 3 * C, C, 0);
+    add(wqkv_f, 0, 0, 1, 3 * C, C, ks);
+    add(wproj_f, 1, 0, 1, C, C, ks);
+    add(wmlp_f, 2, 0, 2, C, C, ks);
+    if (with_natural && wmlp_f) add((bf16_t*)wmlp_f + img, 2, 0, 1, C, C, ks);
+    add(wqkv_t, 0, 1, 1, C, 3 * C, ks3);
+    add(wmlp_t, 2, 1, 1, C, C, ks);
+    add(wproj_t, 1, 1, 2, C, C, ks);
+    if (with_natural && wproj_t) add((bf16_t*)wproj_t + img, 1, 1, 1, C, C, ks);
+    (void)ct3;
+    long total = 0;
+    for (int j = 0; j < jobs.n; ++j) total += jobs.job[j].elems;
+    if (total == 0) return MIVP_OK;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_pack_block_weights, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs);
+    return mivp_check_launch("pack_block_weights");
+}
 
 extern "C" int mivp_pack_weight_frags(const void* w, int32_t rows, int32_t cols, int32_t k_steps, int32_t paired, void* out,
                                       mivp_stream_t stream) {

@@ -26,11 +26,11 @@ class SwinBlockWeights:
     ln1_w: torch.Tensor
     ln1_b: torch.Tensor
     wqkv: torch.Tensor          # bf16 [3C, C] row-major (prompt K/V kernels)
-    wproj: torch.Tensor         # bf16 [C, C]  row-major
+    wproj: Optional[torch.Tensor]   # (unused: the kernels read the fragment images below)
     bproj: torch.Tensor
     ln2_w: torch.Tensor
     ln2_b: torch.Tensor
-    wmlp: torch.Tensor          # bf16 [C, C]
+    wmlp: Optional[torch.Tensor]
     bmlp: torch.Tensor
     t_h: torch.Tensor           # f32 [heads, 2w-1], already * embed_dim**-0.5 / 3
     t_w: torch.Tensor
@@ -83,20 +83,23 @@ def weights_from_state(sd, prefix, heads, embed_dim, n_prompt, device, need_bwd=
     ts = None
     if n_prompt:
         ts = ((f("pe.weights_token") @ f("pe.enc_token.0").t())[:, :n_prompt] * scale).contiguous()
-    wqkv = torch.cat([f("attn.to_q.weight"), f("attn.to_k.weight"), f("attn.to_v.weight")], 0)
+    mats = [f("attn.to_q.weight"), f("attn.to_k.weight"), f("attn.to_v.weight"), f("attn.proj.weight"), f("mlp.weight")]
+    Cc = int(mats[0].shape[0])
+    ct, ks = (Cc + 15) // 16, (Cc + 31) // 32
+    img = ct * ks * 512                                  # elements of one [C][C] fragment image
+    two = 2 if Cc in WIDE_C else 1                       # paired (+ natural) images, see paired_and_natural
+    new = lambda n: torch.empty(n, dtype=BF16, device=device)
     w = SwinBlockWeights(
-        heads=heads, ln1_w=f("attn_norm.weight"), ln1_b=f("attn_norm.bias"), wqkv=wqkv.to(BF16).contiguous(),
-        wproj=f("attn.proj.weight").to(BF16).contiguous(), bproj=f("attn.proj.bias"),
-        ln2_w=f("mlp_norm.weight"), ln2_b=f("mlp_norm.bias"), wmlp=f("mlp.weight").to(BF16).contiguous(),
+        heads=heads, ln1_w=f("attn_norm.weight"), ln1_b=f("attn_norm.bias"), wqkv=new(3 * Cc * Cc).view(3 * Cc, Cc),
+        wproj=None, bproj=f("attn.proj.bias"), ln2_w=f("mlp_norm.weight"), ln2_b=f("mlp_norm.bias"), wmlp=None,
         bmlp=f("mlp.bias"), t_h=tabs[0], t_w=tabs[1], t_d=tabs[2], ts=ts)
-    w.wqkv_f = pack_weight_frags(w.wqkv)
-    w.wproj_f = pack_weight_frags(w.wproj)
-    w.wmlp_f = paired_and_natural(w.wmlp)
-    if need_bwd:
-        ct = (w.wqkv.shape[1] + 15) // 16                # k_swin_qkv_bwd<CT> walks ceil(3 * 16 CT / 32) k-steps (C = 8: two)
-        w.wqkv_t = pack_weight_frags(w.wqkv.t(), k_steps=(3 * 16 * ct + 31) // 32)
-        w.wmlp_t = pack_weight_frags(w.wmlp.t())
-        w.wproj_t = paired_and_natural(w.wproj.t())
+    w.wqkv_f, w.wproj_f, w.wmlp_f = new(((3 * Cc + 15) // 16) * ks * 512), new(img), new(two * img)
+    if need_bwd:                                         # k_swin_qkv_bwd<CT> walks ceil(3 * 16 CT / 32) k-steps (C = 8: two)
+        w.wqkv_t, w.wmlp_t, w.wproj_t = new(ct * ((3 * 16 * ct + 31) // 32) * 512), new(img), new(two * img)
+    # one launch for all of them (a step that changes every parameter rebuilt these with ~25 launches per block)
+    L.call("mivp_pack_block_weights", C.c_int32(Cc), *[L.ptr(m) for m in mats], C.c_int32(1 if two == 2 else 0),
+           L.ptr(w.wqkv), L.ptr(w.wqkv_f), L.ptr(w.wproj_f), L.ptr(w.wmlp_f), L.ptr(w.wqkv_t), L.ptr(w.wmlp_t),
+           L.ptr(w.wproj_t), L.stream())
     return w
 
 
