@@ -121,17 +121,20 @@ struct HeadMajor {
 // gather + LayerNorm + QKV                                             [k_swin_qkv_fwd, swin_fwd.hip]
 // ---------------------------------------------------------------------------------------------
 template <int CT>
-__global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_fwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
+__global__ __launch_bounds__(256, CT <= 3 ? 4 : (CT <= 12 ? 3 : 2)) void k_qkv_fwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          const bf16_t* __restrict__ wqkv, bf16_t* __restrict__ q,
                                                          bf16_t* __restrict__ k, bf16_t* __restrict__ v) {
     using G = WideGeom<CT>;
-    constexpr int C = G::C, KS = C / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, XPT = G::XPT, NT3 = 3 * G::NCT;
-    using XI = RowImg<C>;
+    constexpr int C = G::C, KS = G::KS, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, XPT = G::XPT, NT3 = 3 * G::NCT;
+    using XI = RowImg<G::KP>;
     using OI = RowImg<3 * C>;
+    // one column group (C = 48): a wave's B fragments live in registers, so the output image may overlay the input image
+    // (four workgroups per CU instead of two); the barrier below the fragment reads makes that safe
+    constexpr bool OVERLAY = NCG == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ximg = smem;                                           // [ROWS][C]  LayerNorm output (the GEMM's B operand)
-    char* Oimg = Ximg + ROWS * XI::ROWB;                         // [ROWS][3C] q * scale | k * log2 e | v
+    char* Oimg = OVERLAY ? smem : Ximg + ROWS * XI::ROWB;        // [ROWS][3C] q * scale | k * log2 e | v
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const long row0 = (long)blockIdx.x * ROWS;
@@ -172,6 +175,8 @@ __global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_fwd_wide(MivpSwin
             for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((xs[i][e] - mean) * rstd * w4[i][e >> 2][e & 3] + b4[i][e >> 2][e & 3]);
             XI::put8(Ximg, row, 8 * (sub + TPR * i), keep_if(y, src >= -1));      // -1: a zero-pad token still goes through LN (-> beta)
         }
+        if (G::KP != C && sub == 0)
+            for (int c = C; c < G::KP; c += 8) XI::put8(Ximg, row, c, zero8());          // the k-step padding of the B operand
     }
     __syncthreads();
     {   // ---- GEMM: this wave's column tiles of the 3C outputs, two token tiles ----
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_fwd_wide(MivpSwin
         bf16x8 b0[KS], b1[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { b0[s] = XI::frag(Ximg, R0, 32 * s + 8 * g); b1[s] = XI::frag(Ximg, R1, 32 * s + 8 * g); }
+        if (OVERLAY) __syncthreads();
 #pragma unroll
         for (int j = 0; j < NT3; ++j) {
             const int nt = cg + NCG * j;
@@ -487,8 +493,9 @@ __global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_bwd_wide(MivpSwin
                                                          const bf16_t* __restrict__ wqkv_t, const bf16_t* __restrict__ d_t1,
                                                          bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out) {
     using G = WideGeom<CT>;
-    constexpr int C = G::C, K3 = 3 * C, KS3 = K3 / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG, NCT = G::NCT, XPT = G::XPT;
-    using BI = RowImg<K3>;
+    constexpr int C = G::C, K3 = 3 * C, K3P = (K3 + 31) / 32 * 32, KS3 = K3P / 32, ROWS = G::ROWS, TPR = G::TPR, NCG = G::NCG,
+                  NCT = G::NCT, XPT = G::XPT;
+    using BI = RowImg<K3P>;
     using RI = RowImg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Bimg = smem;                                                   // [ROWS][3C] = dq * scale | dk | dv of the token
@@ -538,7 +545,11 @@ __global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_bwd_wide(MivpSwin
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float dvv = xs[i][e] - mean; var += dvv * dvv; }
         const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
-        if (sub == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
+        if (sub == 0) {
+            stat[2 * row] = mean;
+            stat[2 * row + 1] = rstd;
+            for (int c = K3; c < K3P; c += 8) BI::put8(Bimg, row, c, zero8());           // the k-step padding of the B operand
+        }
     }
     __syncthreads();
 
@@ -626,7 +637,11 @@ __global__ __launch_bounds__(256, CT <= 12 ? 3 : 2) void k_qkv_bwd_wide(MivpSwin
     }
 }
 
-template <int CT> size_t lds_qkv_fwd() { using G = WideGeom<CT>; return (size_t)G::ROWS * (RowImg<G::C>::ROWB + RowImg<3 * G::C>::ROWB); }
+template <int CT> size_t lds_qkv_fwd() {
+    using G = WideGeom<CT>;
+    const size_t xi = (size_t)G::ROWS * RowImg<G::KP>::ROWB, oi = (size_t)G::ROWS * RowImg<3 * G::C>::ROWB;
+    return G::NCG == 1 ? (xi > oi ? xi : oi) : xi + oi;
+}
 template <int CT> size_t lds_proj_mlp_fwd() { using G = WideGeom<CT>; return (size_t)G::ROWS * 2 * RowImg<G::KP>::ROWB; }
 template <int CT> size_t lds_proj_mlp_bwd() {
     using G = WideGeom<CT>;
@@ -634,7 +649,7 @@ template <int CT> size_t lds_proj_mlp_bwd() {
 }
 template <int CT> size_t lds_qkv_bwd() {
     using G = WideGeom<CT>;
-    return (size_t)G::ROWS * (RowImg<3 * G::C>::ROWB + RowImg<G::C>::ROWB) + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float);
+    return (size_t)G::ROWS * (RowImg<(3 * G::C + 31) / 32 * 32>::ROWB + RowImg<G::C>::ROWB) + (2 * G::ROWS + 2 * G::ROWS * G::NCG) * sizeof(float);
 }
 
 // w row-major [rows][cols] -> fragment image [rows/16 (up)][k_steps][64 lanes][8]
@@ -749,9 +764,12 @@ extern "C" int mivp_pack_weight_frags(const void* w, int32_t rows, int32_t cols,
 // C = 96 / 192 / 384, windows of a multiple of 32 slots (a 32-token granule then never leaves its window)
 int mivp_tok_wide_supported(const MivpSwinDesc* d) {
     const int hd = d->C / d->heads;
-    if (!(d->C == 96 || d->C == 192 || d->C == 384)) return 0;
+    if (!(d->C == 48 || d->C == 96 || d->C == 192 || d->C == 384)) return 0;
     static const bool off = getenv("MIVP_NO_WIDE_TOKEN_KERNELS") != nullptr;     // A/B switch for profiling and tests
     if (off) return 0;
+    // C = 48: the QKV pair measured SLOWER in this form (forward 55 vs 50 us, backward 88 vs 77 us at 48^3 x 4: the
+    // head-major piece decode, the LDS round trip and half the occupancy cost more than the contiguous stores save); opt-in
+    if (d->C == 48 && !getenv("MIVP_C48_QKV_ROW_KERNELS")) return 0;
     return (hd % 4 == 0 && d->Nqp % 32 == 0 && 8 * hd < 65536 && 72 * d->C < 65536) ? 1 : 0;
 }
 // the proj / MLP pair in the same form also at C = 48 (one column group: a wave owns its 32 tokens' three column tiles)
@@ -790,7 +808,7 @@ int mivp_tok_wide_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* t
         hipLaunchKernelGGL((k_qkv_fwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)x, tok_src, ln_w,   \
                            ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v);                                   \
     } while (0)
-    WIDE_SWITCH(L_W)
+    ROWS_SWITCH(L_W)
 #undef L_W
     return mivp_check_launch("swin_qkv_fwd(wide)");
 }
@@ -839,7 +857,7 @@ int mivp_tok_wide_qkv_bwd(const MivpSwinDesc* d, const void* dq, const void* dk,
                            (const bf16_t*)dv, (const bf16_t*)x, tok_src, ln_w, (const bf16_t*)wqkv_t, (const bf16_t*)d_t1,   \
                            (bf16_t*)dx, (bf16_t*)dn_out);                                                                    \
     } while (0)
-    WIDE_SWITCH(L_W)
+    ROWS_SWITCH(L_W)
 #undef L_W
     return mivp_check_launch("swin_qkv_bwd(wide)");
 }
