@@ -291,6 +291,47 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
     const bf16_t* kab = ka + (long)head * Nkp * A;
     const bf16_t* dob = d_o + bp * (long)Nqp * C + head * hd;
     const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+    // This wave's Q' / dO fragments do not depend on the key chunk: loaded ONCE, unconditionally and back to back (they
+    // used to be re-read for every chunk by one conditional load -- one memory round trip -- per 8-byte piece: 8 dependent
+    // round trips in front of every query tile's key loop).  common.hpp "Branch-free loads".
+    bf16x8 qf_all[QPW][DKS];
+    bf16x8 dof_all[QPW][DVS];
+    bf16x4 dof4_all[QPW];
+    {
+        const long to_qa = qa - qb;
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) {
+            const int qt = wave + NW * i;
+            const int qrow = (qt < nqt ? qt : 0) * 16 + r;
+#pragma unroll
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf;
+                    const int ca = min(max(c4 - hd4, 0), a4 - 1);
+                    const long off = sel(c4 < hd4, (long)(qrow * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(qrow * A + 4 * ca));
+                    piece[hlf] = keep_if(ld4(qb + off), c4 < hd4 + a4);
+                }
+                qf_all[i][s] = cat44(piece[0], piece[1]);
+            }
+            dof4_all[i] = zero4();
+            if (G::V16) {
+                dof4_all[i] = keep_if(ld4(dob + ((uint32_t)qrow * C + 4 * min(g, hd4 - 1))), g < hd4);
+            } else {
+#pragma unroll
+                for (int s = 0; s < DVS; ++s) {
+                    bf16x4 piece[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int c4 = 8 * s + 2 * g + hlf;
+                        piece[hlf] = keep_if(ld4(dob + ((uint32_t)qrow * C + 4 * min(c4, hd4 - 1))), c4 < hd4);
+                    }
+                    dof_all[i][s] = cat44(piece[0], piece[1]);
+                }
+            }
+        }
+    }
     // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op
     bool cut = false;
     if (MASKED) {
@@ -351,36 +392,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
             const int qt = wave + NW * i;
             if (qt >= nqt) continue;
             const int qrow = qt * 16 + r;
-            bf16x8 qf[DKS];
-#pragma unroll
-            for (int s = 0; s < DKS; ++s) {
-                bf16x4 piece[2];
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int c4 = 8 * s + 2 * g + hlf;
-                    bf16x4 val = zero4();
-                    if (c4 < hd4) val = ld4(qb + ((uint32_t)qrow * hd + 4 * c4));
-                    else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)qrow * A + 4 * (c4 - hd4)));
-                    piece[hlf] = val;
-                }
-                qf[s] = cat44(piece[0], piece[1]);
-            }
-            bf16x8 dof[DVS];
-            bf16x4 dof4 = zero4();
-            if (G::V16) {
-                if (g < hd4) dof4 = ld4(dob + ((uint32_t)qrow * C + 4 * g));
-            } else {
-#pragma unroll
-                for (int s = 0; s < DVS; ++s) {
-                    bf16x4 piece[2];
-#pragma unroll
-                    for (int hlf = 0; hlf < 2; ++hlf) {
-                        const int c4 = 8 * s + 2 * g + hlf;
-                        piece[hlf] = c4 < hd4 ? ld4(dob + ((uint32_t)qrow * C + 4 * c4)) : zero4();
-                    }
-                    dof[s] = cat44(piece[0], piece[1]);
-                }
-            }
+            const bf16x8 (&qf)[DKS] = qf_all[i];
+            const bf16x8 (&dof)[DVS] = dof_all[i];
+            const bf16x4 dof4 = dof4_all[i];
             const int rqi = rq[i];
             const float lsei = lse_b[i], dli = dl[i];
             const uint32_t drow = DROP ? attn_row(bph, qrow, Nqp, Nkp) : 0u;
@@ -528,6 +542,48 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
     const float* lseb = lse + bph * (long)Nqp;
     const float* delb = delta + bph * (long)Nqp;
     const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+    // This wave's K' / V fragments and key classes do not depend on the query chunk: loaded once, unconditionally and back to
+    // back (see the dq kernel).
+    bf16x8 kf_all[KPW][DKS];
+    bf16x8 vf_all[KPW][DVS];
+    bf16x4 vf4_all[KPW];
+    int kcls_all[KPW];
+    {
+        const long to_kp = kpb - kb, to_ka = kab - kb, to_vp = vpb - vb;
+        const int max_prow = n_prompt_rows > 0 ? n_prompt_rows - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int kt = kfirst + kstride * i;
+            const int krow = (kt < nt ? kt : 0) * 16 + r;
+            const bool staged = krow < Nqp + n_prompt_rows;
+            const int pr = min(max(krow - Nqp, 0), max_prow);
+            kcls_all[i] = sel(krow < d.Nq, d.has_mask ? tok_rid[pw * Nqp + min(krow, d.Nq - 1)] : 0, -2);
+#pragma unroll
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf, cc = min(c4, hd4 - 1);
+                    const int ca = min(max(c4 - hd4, 0), a4 - 1);
+                    const long off_k = sel(krow < Nqp, (long)(krow * hd + 4 * cc), to_kp + (long)(pr * hd + 4 * cc));
+                    const long off = sel(c4 < hd4, off_k, to_ka + (long)(krow * A + 4 * ca));
+                    piece[hlf] = keep_if(ld4(kb + off), sel(c4 < hd4, (int)staged, (int)(c4 < hd4 + a4)) != 0);
+                }
+                kf_all[i][s] = cat44(piece[0], piece[1]);
+            }
+            auto vload = [&](int c4) -> bf16x4 {
+                const int cc = min(c4, hd4 - 1);
+                const long off = sel(krow < Nqp, (long)(krow * hd + 4 * cc), to_vp + (long)(pr * hd + 4 * cc));
+                return keep_if(ld4(vb + off), c4 < hd4 && staged);
+            };
+            vf4_all[i] = zero4();
+            if (G::V16) vf4_all[i] = vload(g);
+            else {
+#pragma unroll
+                for (int s = 0; s < DVS; ++s) vf_all[i][s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
+            }
+        }
+    }
     // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op and the
     // workgroup takes the un-shifted block's lean path
     bool cut = false;
@@ -591,42 +647,11 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                 const int kt = kfirst + kstride * i;
                 if (kt >= nt) continue;
                 const int krow = kt * 16 + r;
-                // content key: region id; prompt and padding keys: -2 = never masked (padding keys are excluded by their bias)
-                const int kcls = krow < d.Nq ? (d.has_mask ? tok_rid[pw * Nqp + krow] : 0) : -2;
+                const int kcls = kcls_all[i];                 // content key: region id; prompt / padding keys: -2 = never masked
                 const uint32_t dbase = DROP ? attn_row(bph, 0, Nqp, Nkp) : 0u;
-                bf16x8 kf[DKS];
-#pragma unroll
-                for (int s = 0; s < DKS; ++s) {
-                    bf16x4 piece[2];
-#pragma unroll
-                    for (int hlf = 0; hlf < 2; ++hlf) {
-                        const int c4 = 8 * s + 2 * g + hlf;
-                        bf16x4 val = zero4();
-                        if (c4 < hd4) {
-                            if (krow < Nqp) val = ld4(kb + ((uint32_t)krow * hd + 4 * c4));
-                            else if (krow < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
-                        } else if (c4 < hd4 + a4) {
-                            val = ld4(kab + ((uint32_t)krow * A + 4 * (c4 - hd4)));
-                        }
-                        piece[hlf] = val;
-                    }
-                    kf[s] = cat44(piece[0], piece[1]);
-                }
-                auto vload = [&](int c4) -> bf16x4 {
-                    bf16x4 val = zero4();
-                    if (c4 < hd4) {
-                        if (krow < Nqp) val = ld4(vb + ((uint32_t)krow * hd + 4 * c4));
-                        else if (krow < Nqp + n_prompt_rows) val = ld4(vpb + ((uint32_t)(krow - Nqp) * hd + 4 * c4));
-                    }
-                    return val;
-                };
-                bf16x8 vf[DVS];
-                bf16x4 vf4 = zero4();
-                if (G::V16) vf4 = vload(g);
-                else {
-#pragma unroll
-                    for (int s = 0; s < DVS; ++s) vf[s] = cat44(vload(8 * s + 2 * g), vload(8 * s + 2 * g + 1));
-                }
+                const bf16x8 (&kf)[DKS] = kf_all[i];
+                const bf16x8 (&vf)[DVS] = vf_all[i];
+                const bf16x4 vf4 = vf4_all[i];
                 // A key tile made of prompt / padding keys only is never masked: it takes the lean path even in a cut window.
                 // Elsewhere "live" = (key class == query region) | (prompt or padding key) is ONE compare on pre-or-ed
                 // operands -- (rq | pm) == kk with pm = all ones and kk = all ones for prompt / padding lanes -- so that no
