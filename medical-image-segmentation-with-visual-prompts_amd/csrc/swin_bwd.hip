@@ -344,23 +344,33 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
         const int ntc = (nt - t0) < chunk_tiles ? (nt - t0) : chunk_tiles;       // tiles in this chunk (even)
         const int key0 = t0 * 16, nkeys = ntc * 16;
         __syncthreads();
-        {   // K' rows (+ K^T of the head dims): a thread keeps one 8-byte column of the image; 32-bit offsets from uniform bases
+        {   // K' rows (+ K^T of the head dims): a thread keeps one 8-byte column of the image; four unconditional loads in
+            // flight per thread before the first LDS write (clamped rows: the ragged tail rewrites the last row)
             constexpr int RPP = 64 * NW / dk4;
             const int c4 = tid % dk4;
             const bool from_k = c4 < hd4, from_a = !from_k && c4 < hd4 + a4;
-            const bf16_t* src = from_k ? kb : kab;
-            const uint32_t stride = from_k ? hd : A, coff = from_k ? 4 * c4 : 4 * (c4 - hd4);
-            const int rows_main = from_k ? Nqp : (from_a ? Nkp : 0);
-            for (int lrow = tid / dk4; lrow < nkeys; lrow += RPP) {
-                const int row = key0 + lrow;
-                bf16x4 val = zero4();
-                if (row < rows_main) val = ld4(src + ((uint32_t)row * stride + coff));
-                else if (from_k && row < Nqp + n_prompt_rows) val = ld4(kpb + ((uint32_t)(row - Nqp) * hd + coff));
-                if (from_k) {
+            const int cc = min(c4, hd4 - 1), ca = min(max(c4 - hd4, 0), a4 - 1);
+            const long to_kp = kpb - kb, to_ka = kab - kb;
+            const int max_prow = n_prompt_rows > 0 ? n_prompt_rows - 1 : 0;
+            for (int rowb = tid / dk4; rowb < nkeys; rowb += 4 * RPP) {
+                bf16x4 vals[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + i) * KTROW + 2 * lrow) = val[i];
+                for (int i = 0; i < 4; ++i) {
+                    const int row = key0 + min(rowb + i * RPP, nkeys - 1);
+                    const int pr = min(max(row - Nqp, 0), max_prow);
+                    const long off_k = sel(row < Nqp, (long)(row * hd + 4 * cc), to_kp + (long)(pr * hd + 4 * cc));
+                    const long off = sel(from_k, off_k, to_ka + (long)(row * A + 4 * ca));
+                    vals[i] = keep_if(ld4(kb + off), sel(from_k, (int)(row < Nqp + n_prompt_rows), (int)from_a) != 0);
                 }
-                *reinterpret_cast<bf16x4*>(Kimg + G::KR::off(lrow, 4 * c4)) = val;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int lrow = min(rowb + i * RPP, nkeys - 1);
+                    if (from_k) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16_t*>(Kt + (size_t)(4 * c4 + e) * KTROW + 2 * lrow) = vals[i][e];
+                    }
+                    *reinterpret_cast<bf16x4*>(Kimg + G::KR::off(lrow, 4 * c4)) = vals[i];
+                }
             }
         }
         // K^T rows between hd and 16*DVT must be zero (they multiply dS in the dq MFMA)
@@ -370,15 +380,21 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
         }
         {
             constexpr int RPP = 64 * NW / dvp4;
-            const int c4 = tid % dvp4;
-            for (int lrow = tid / dvp4; lrow < nkeys; lrow += RPP) {
-                const int row = key0 + lrow;
-                bf16x4 val = zero4();
-                if (c4 < hd4) {
-                    if (row < Nqp) val = ld4(vb + ((uint32_t)row * hd + 4 * c4));
-                    else if (row < Nqp + n_prompt_rows) val = ld4(vpb + ((uint32_t)(row - Nqp) * hd + 4 * c4));
+            const int c4 = tid % dvp4, cc = min(c4, hd4 - 1);
+            const long to_vp = vpb - vb;
+            const int max_prow = n_prompt_rows > 0 ? n_prompt_rows - 1 : 0;
+            for (int rowb = tid / dvp4; rowb < nkeys; rowb += 4 * RPP) {
+                bf16x4 vals[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = key0 + min(rowb + i * RPP, nkeys - 1);
+                    const int pr = min(max(row - Nqp, 0), max_prow);
+                    const long off = sel(row < Nqp, (long)(row * hd + 4 * cc), to_vp + (long)(pr * hd + 4 * cc));
+                    vals[i] = keep_if(ld4(vb + off), c4 < hd4 && row < Nqp + n_prompt_rows);
                 }
-                *reinterpret_cast<bf16x4*>(Vimg + (size_t)lrow * VROWB + 8 * c4) = val;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<bf16x4*>(Vimg + (size_t)min(rowb + i * RPP, nkeys - 1) * VROWB + 8 * c4) = vals[i];
             }
         }
         for (int m = tid; m < nkeys; m += 64 * NW) {
@@ -597,24 +613,37 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
         const int ntc = (nqt - t0) < chunk_tiles ? (nqt - t0) : chunk_tiles;
         const int q0 = t0 * 16, nq = ntc * 16;
         __syncthreads();
-        for (int e = tid; e < nq * dk4; e += 64 * NW) {
-            const int lrow = e / dk4, c4 = e - lrow * dk4, row = q0 + lrow;
-            bf16x4 val = zero4();
-            if (row < Nqp) {
-                if (c4 < hd4) val = ld4(qb + ((uint32_t)row * hd + 4 * c4));
-                else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)row * A + 4 * (c4 - hd4)));
-            }
-            if (c4 < 4 * DVT) {
+        {   // Q' rows (+ Q^T): four unconditional loads in flight per thread before the first LDS write
+            const long to_qa = qa - qb;
+            const int n_e = nq * dk4;
+            for (int e0 = tid; e0 < n_e; e0 += 4 * 64 * NW) {
+                bf16x4 vals[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<bf16_t*>(Qt + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = (c4 < hd4) ? val[i] : (bf16_t)0.0f;
-            }
-            if (AUG && c4 >= hd4 && c4 < hd4 + a4) {
+                for (int i = 0; i < 4; ++i) {
+                    const int e = min(e0 + i * 64 * NW, n_e - 1);
+                    const int lrow = e / dk4, c4 = e - lrow * dk4, row = min(q0 + lrow, Nqp - 1);
+                    const int ca = min(max(c4 - hd4, 0), a4 - 1);
+                    const long off = sel(c4 < hd4, (long)(row * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(row * A + 4 * ca));
+                    vals[i] = keep_if(ld4(qb + off), q0 + lrow < Nqp && c4 < hd4 + a4);
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<bf16_t*>(Qt + (size_t)(16 * DVT + 4 * (c4 - hd4) + i) * TROW + 2 * lrow) = val[i];
+                for (int i = 0; i < 4; ++i) {
+                    const int e = min(e0 + i * 64 * NW, n_e - 1);
+                    const int lrow = e / dk4, c4 = e - lrow * dk4;
+                    const bf16x4 val = vals[i];
+                    if (c4 < 4 * DVT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<bf16_t*>(Qt + (size_t)(4 * c4 + j) * TROW + 2 * lrow) = (c4 < hd4) ? val[j] : (bf16_t)0.0f;
+                    }
+                    if (AUG && c4 >= hd4 && c4 < hd4 + a4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<bf16_t*>(Qt + (size_t)(16 * DVT + 4 * (c4 - hd4) + j) * TROW + 2 * lrow) = val[j];
+                    }
+                    *reinterpret_cast<bf16x4*>(Qimg + G::KR::off(lrow, 4 * c4)) = val;
+                }
             }
-            *reinterpret_cast<bf16x4*>(Qimg + G::KR::off(lrow, 4 * c4)) = val;
         }
         if (AUG) {                                             // augmentation rows A .. 31 of the transposed image are zero
             for (int e = tid; e < (32 - A) * nq; e += 64 * NW) {
@@ -622,15 +651,27 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                 *reinterpret_cast<bf16_t*>(Qt + (size_t)rr * TROW + 2 * col) = (bf16_t)0.0f;
             }
         }
-        for (int e = tid; e < nq * dvp4; e += 64 * NW) {
-            const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = q0 + lrow;
-            bf16x4 val = zero4();
-            if (row < Nqp && c4 < hd4) val = ld4(dob + ((uint32_t)row * C + 4 * c4));
-            if (c4 < 4 * DVT) {
+        {
+            const int n_e = nq * dvp4;
+            for (int e0 = tid; e0 < n_e; e0 += 4 * 64 * NW) {
+                bf16x4 vals[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(Ot + (size_t)(4 * c4 + i) * TROW + 2 * lrow) = val[i];
+                for (int i = 0; i < 4; ++i) {
+                    const int e = min(e0 + i * 64 * NW, n_e - 1);
+                    const int lrow = e / dvp4, c4 = e - lrow * dvp4, row = min(q0 + lrow, Nqp - 1);
+                    vals[i] = keep_if(ld4(dob + ((uint32_t)row * C + 4 * min(c4, hd4 - 1))), q0 + lrow < Nqp && c4 < hd4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = min(e0 + i * 64 * NW, n_e - 1);
+                    const int lrow = e / dvp4, c4 = e - lrow * dvp4;
+                    if (c4 < 4 * DVT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16_t*>(Ot + (size_t)(4 * c4 + j) * TROW + 2 * lrow) = vals[i][j];
+                    }
+                    *reinterpret_cast<bf16x4*>(Oimg + (size_t)lrow * OROW + 8 * c4) = vals[i];
+                }
             }
-            *reinterpret_cast<bf16x4*>(Oimg + (size_t)lrow * OROW + 8 * c4) = val;
         }
         for (int m = tid; m < nq; m += 64 * NW) {
             const int row = q0 + m;
