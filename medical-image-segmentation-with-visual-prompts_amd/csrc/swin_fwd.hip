@@ -379,6 +379,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
     const int nqt = Nqp / 16;
     const bf16_t* qb = q + bph * (long)Nqp * hd;
     bf16_t* ob = o + bp * (long)Nqp * C + head * hd;
+    // Q' fragments (+ region ids) of a query tile: unconditional loads (common.hpp "Branch-free loads"), issued ONE TILE AHEAD:
+    // written as conditional loads in the tile's prologue they were 2-3 dependent memory round trips in front of every
+    // ~1 us key loop of the wave.
+    const long to_qa = qa - qb;
+    auto load_q = [&](int qt_first, bf16x8 (&qfo)[QT][DKS], uint32_t (&rqo)[QT]) {
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            const int qt = (qt_first + a < nqt) ? qt_first + a : (qt_first < nqt ? qt_first : 0);
+            const int row = qt * 16 + r;
+            rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, tok_rid[pw * Nqp + min(row, d.Nq - 1)], 0) : 0u;
+#pragma unroll
+            for (int s = 0; s < DKS; ++s) {
+                bf16x4 piece[2];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c4 = 8 * s + 2 * g + hlf;
+                    const int ca = min(max(c4 - hd4, 0), a4 - 1);
+                    const long off = sel(c4 < hd4, (long)(row * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(row * A + 4 * ca));
+                    piece[hlf] = keep_if(ld4(qb + off), c4 < hd4 + a4);
+                }
+                qfo[a][s] = cat44(piece[0], piece[1]);
+            }
+        }
+    };
+    bf16x8 qf_next[QT][DKS];
+    uint32_t rq_next[QT];
+    load_q(QT * wave, qf_next, rq_next);
     for (int qt0 = QT * wave; qt0 < nqt; qt0 += QT * NW) {
         int qrow[QT];
         uint32_t rq[QT];
@@ -390,21 +417,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
         for (int a = 0; a < QT; ++a) {
             const int qt = (qt0 + a < nqt) ? qt0 + a : qt0;  // an odd tile count: the spare slot shadows tile qt0, nothing stored
             qrow[a] = qt * 16 + r;
-            rq[a] = (MASKED && qrow[a] < d.Nq) ? (uint32_t)tok_rid[pw * Nqp + qrow[a]] : 0u;
-            // Q' fragment straight from global: [head dims | bias one-hots | zero pad], 4 elements at a time
+            rq[a] = rq_next[a];
 #pragma unroll
-            for (int s = 0; s < DKS; ++s) {
-                bf16x4 piece[2];
+            for (int s = 0; s < DKS; ++s) qf[a][s] = qf_next[a][s];
+        }
+        load_q(qt0 + QT * NW, qf_next, rq_next);              // the next tile's operands travel under this tile's key loop
 #pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int c4 = 8 * s + 2 * g + hlf;
-                    bf16x4 val = zero4();
-                    if (c4 < hd4) val = ld4(qb + ((uint32_t)qrow[a] * hd + 4 * c4));
-                    else if (c4 < hd4 + a4) val = ld4(qa + ((uint32_t)qrow[a] * A + 4 * (c4 - hd4)));
-                    piece[hlf] = val;
-                }
-                qf[a][s] = cat44(piece[0], piece[1]);
-            }
+        for (int a = 0; a < QT; ++a) {
 #pragma unroll
             for (int dd = 0; dd < DVT; ++dd) oacc[a][dd] = fzero4();
             negm[a] = fzero4();
