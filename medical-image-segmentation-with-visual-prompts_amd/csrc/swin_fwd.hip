@@ -199,6 +199,65 @@ __global__ __launch_bounds__(256) void k_prompt_kv_fwd(MivpSwinDesc d, const flo
     }
 }
 
+// K2 for several blocks in one launch (blockIdx.y = block), which also writes the prompt-token bias ts into the i0 one-hot
+// columns of the block's K'-augmentation image: with frozen content tables everything else in that image is constant, so
+// a prompted block's per-step small forward work is this launch plus the (equally batched) token scores -- instead of
+// token scores + mivp_relbias_aug + mivp_prompt_kv_fwd per block.
+struct PromptKvJob {
+    MivpSwinDesc d;
+    const float* prompt; const float* ln_w; const float* ln_b; const bf16_t* wqkv; const float* ts;
+    bf16_t* kp; bf16_t* vp; bf16_t* ka;
+};
+struct PromptKvJobs { PromptKvJob job[16]; };
+__global__ __launch_bounds__(256) void k_prompt_kv_fwd_multi(PromptKvJobs jobs) {
+    const PromptKvJob& jb = jobs.job[blockIdx.y];
+    const MivpSwinDesc& d = jb.d;
+    const int t = blockIdx.x;
+    if (t >= d.Npp) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* y = reinterpret_cast<float*>(smem);             // [C]
+    float* red = y + d.C;                                   // [8]
+    const int C = d.C, hd = C / d.heads;
+    const int tid = threadIdx.x;
+    const float* __restrict__ prompt = jb.prompt;
+    if (t >= d.Np) {                                        // zero the padding rows
+        for (int n = tid; n < 2 * C; n += 256) {
+            const int sel = n / C, cc = n - sel * C, head = cc / hd, j = cc - head * hd;
+            (sel == 0 ? jb.kp : jb.vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)0.0f;
+        }
+        return;
+    }
+    // prompt-token bias: ka[head][Nqp + t][a < w0] = ts[head][t] * log2 e (mivp_relbias_aug's prompt rows)
+    for (int n = tid; n < d.heads * d.win[0]; n += 256) {
+        const int head = n / d.win[0], a = n - head * d.win[0];
+        jb.ka[((long)head * d.Nkp + d.Nqp + t) * d.augp + a] = (bf16_t)(jb.ts[(long)head * d.Np + t] * MIVP_LOG2E);
+    }
+    float part = 0.f;
+    for (int c = tid; c < C; c += 256) part += prompt[(long)t * C + c];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    __syncthreads();
+    part = 0.f;
+    for (int c = tid; c < C; c += 256) { const float dv = prompt[(long)t * C + c] - mean; part += dv * dv; }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = part;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + d.ln_eps);
+    for (int c = tid; c < C; c += 256)
+        y[c] = (float)(bf16_t)((prompt[(long)t * C + c] - mean) * rstd * jb.ln_w[c] + jb.ln_b[c]);   // same rounding point as the window tokens
+    __syncthreads();
+    for (int n = tid; n < 2 * C; n += 256) {
+        const int sel = n / C, cc = n - sel * C;
+        const bf16_t* wrow = jb.wqkv + (long)((sel + 1) * C + cc) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += y[c] * (float)wrow[c];
+        const int head = cc / hd, j = cc - head * hd;
+        (sel == 0 ? jb.kp : jb.vp)[((long)head * d.Npp + t) * hd + j] = (bf16_t)(sel == 0 ? acc * MIVP_LOG2E : acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3  relative-position bias -> augmentation columns of Q' / K'
 //   bias[n,m] = Th[k0-i0+w0-1] + Tw[k1-i1+w1-1] + Td[k2-i2+w2-1]   (tables pre-scaled by s/3)
@@ -824,6 +883,29 @@ extern "C" int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, co
     hipLaunchKernelGGL(k_prompt_kv_fwd, dim3(d->Npp), dim3(256), (d->C + 8) * sizeof(float), (hipStream_t)stream, *d,
                        prompt, ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)kp, (bf16_t*)vp, yln);
     return mivp_check_launch("prompt_kv_fwd");
+}
+
+/* n <= 16 blocks, arrays of n entries each (host memory); descriptors need C, heads, Np, Npp, Nqp, Nkp, augp, win, ln_eps.
+ * ka[i]: the block's K'-augmentation image as mivp_relbias_aug wrote it for ts = 0 (its prompt rows are rewritten here). */
+extern "C" int mivp_prompt_kv_fwd_multi(int32_t n, const MivpSwinDesc* d, const float* const* prompt, const float* const* ln_w,
+                                        const float* const* ln_b, const void* const* wqkv, const float* const* ts,
+                                        void* const* kp, void* const* vp, void* const* ka, mivp_stream_t stream) {
+    MIVP_REQUIRE(n > 0 && n <= 16 && d && prompt && ln_w && ln_b && wqkv && ts && kp && vp && ka);
+    PromptKvJobs jobs;
+    int rows = 0;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = swin_common_checks(&d[i]);
+        if (rc) return rc;
+        MIVP_REQUIRE(d[i].Np > 0 && prompt[i] && ln_w[i] && ln_b[i] && wqkv[i] && ts[i] && kp[i] && vp[i] && ka[i]);
+        jobs.job[i] = PromptKvJob{d[i], prompt[i], ln_w[i], ln_b[i], (const bf16_t*)wqkv[i], ts[i], (bf16_t*)kp[i], (bf16_t*)vp[i],
+                                  (bf16_t*)ka[i]};
+        rows = d[i].Npp > rows ? d[i].Npp : rows;
+        const size_t need = (d[i].C + 8) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    hipLaunchKernelGGL(k_prompt_kv_fwd_multi, dim3(rows, n), dim3(256), lds, (hipStream_t)stream, jobs);
+    return mivp_check_launch("prompt_kv_fwd_multi");
 }
 
 extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, const float* t_d,

@@ -131,6 +131,88 @@ __global__ __launch_bounds__(256) void k_token_scores_bwd(const float* __restric
     }
 }
 
+// The same for several blocks in ONE launch (blockIdx.x = block): these kernels last 5-10 us each whatever they compute, and
+// a prompt-tuning step runs one per prompted block and direction.
+struct TokenScoreJob { const float* W; const float* E; const float* dts; float* ts; float* dW; float* dE; int heads, np, e; float scale; };
+struct TokenScoreJobs { TokenScoreJob job[16]; };
+__global__ __launch_bounds__(256) void k_token_scores_fwd_multi(TokenScoreJobs jobs) {
+    const TokenScoreJob& jb = jobs.job[blockIdx.x];
+    const float* __restrict__ W = jb.W;
+    const float* __restrict__ E = jb.E;
+    const int heads = jb.heads, np = jb.np, e = jb.e;
+    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+    float* Ws = reinterpret_cast<float*>(smem_ts);             // [heads][e + 1]
+    float* Es = Ws + heads * (e + 1);                          // [np][e + 1]
+    for (int i = threadIdx.x; i < heads * e; i += 256) Ws[(i / e) * (e + 1) + i % e] = W[i];
+    for (int i = threadIdx.x; i < np * e; i += 256) Es[(i / e) * (e + 1) + i % e] = E[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * np; i += 256) {
+        const int h = i / np, t = i - h * np;
+        float acc = 0.f;
+        for (int k = 0; k < e; ++k) acc += Ws[h * (e + 1) + k] * Es[t * (e + 1) + k];
+        jb.ts[i] = acc * jb.scale;
+    }
+}
+__global__ __launch_bounds__(256) void k_token_scores_bwd_multi(TokenScoreJobs jobs) {
+    const TokenScoreJob& jb = jobs.job[blockIdx.x];
+    const int heads = jb.heads, np = jb.np, e = jb.e;
+    const float scale = jb.scale;
+    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+    float* Ws = reinterpret_cast<float*>(smem_ts);             // [heads][e]
+    float* Es = Ws + heads * e;                                // [np][e]
+    float* Ds = Es + np * e;                                   // [heads][np]
+    for (int i = threadIdx.x; i < heads * e; i += 256) Ws[i] = jb.W[i];
+    for (int i = threadIdx.x; i < np * e; i += 256) Es[i] = jb.E[i];
+    for (int i = threadIdx.x; i < heads * np; i += 256) Ds[i] = jb.dts ? jb.dts[i] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * e; i += 256) {       // dW[h][k] = scale * sum_t dts[h][t] E[t][k]
+        const int h = i / e, k = i - h * e;
+        float acc = 0.f;
+        for (int t = 0; t < np; ++t) acc += Ds[h * np + t] * Es[t * e + k];
+        jb.dW[i] = acc * scale;
+    }
+    for (int i = threadIdx.x; i < np * e; i += 256) {          // dE[t][k] = scale * sum_h dts[h][t] W[h][k]
+        const int t = i / e, k = i - t * e;
+        float acc = 0.f;
+        for (int h = 0; h < heads; ++h) acc += Ds[h * np + t] * Ws[h * e + k];
+        jb.dE[i] = acc * scale;
+    }
+}
+
+/* n <= 16 blocks; arrays of n entries each (host memory).  bwd: dts[i] may be NULL (no gradient reached that block). */
+extern "C" int mivp_token_scores_fwd_multi(int32_t n, const float* const* W, const float* const* E, const int32_t* heads,
+                                           const int32_t* np, int32_t e, const float* scale, float* const* ts,
+                                           mivp_stream_t stream) {
+    MIVP_REQUIRE(n > 0 && n <= 16 && W && E && heads && np && scale && ts && e > 0);
+    TokenScoreJobs jobs;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        MIVP_REQUIRE(W[i] && E[i] && ts[i] && heads[i] > 0 && np[i] > 0);
+        jobs.job[i] = TokenScoreJob{W[i], E[i], nullptr, ts[i], nullptr, nullptr, heads[i], np[i], e, scale[i]};
+        const size_t need = (size_t)(heads[i] + np[i]) * (e + 1) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    MIVP_REQUIRE(lds <= 64 * 1024);
+    hipLaunchKernelGGL(k_token_scores_fwd_multi, dim3(n), dim3(256), lds, (hipStream_t)stream, jobs);
+    return mivp_check_launch("token_scores_fwd_multi");
+}
+extern "C" int mivp_token_scores_bwd_multi(int32_t n, const float* const* dts, const float* const* W, const float* const* E,
+                                           const int32_t* heads, const int32_t* np, int32_t e, const float* scale,
+                                           float* const* dW, float* const* dE, mivp_stream_t stream) {
+    MIVP_REQUIRE(n > 0 && n <= 16 && dts && W && E && heads && np && scale && dW && dE && e > 0);
+    TokenScoreJobs jobs;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        MIVP_REQUIRE(W[i] && E[i] && dW[i] && dE[i] && heads[i] > 0 && np[i] > 0);
+        jobs.job[i] = TokenScoreJob{W[i], E[i], dts[i], nullptr, dW[i], dE[i], heads[i], np[i], e, scale[i]};
+        const size_t need = ((size_t)(heads[i] + np[i]) * e + (size_t)heads[i] * np[i]) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    MIVP_REQUIRE(lds <= 64 * 1024);
+    hipLaunchKernelGGL(k_token_scores_bwd_multi, dim3(n), dim3(256), lds, (hipStream_t)stream, jobs);
+    return mivp_check_launch("token_scores_bwd_multi");
+}
+
 extern "C" int mivp_token_scores_fwd(const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale, float* ts,
                                      mivp_stream_t stream) {
     MIVP_REQUIRE(W && E && ts && heads > 0 && np > 0 && e > 0);

@@ -165,9 +165,9 @@ def patch_embed(owner, conv, bn, x):
 # ----------------------------------------------------------------------------------------------
 class _SwinBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, prompt, ts, w, window, shift, dropout):
+    def forward(ctx, x, prompt, ts, w, window, shift, dropout, pre=None):
         need = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=need, dropout=dropout)
+        y, saved = swin_ops.swin_block_forward(x, prompt, w, ts, window, shift, save=need, dropout=dropout, pre=pre)
         ctx.saved = saved
         ctx.w = w
         ctx.has_prompt = prompt is not None
@@ -182,7 +182,7 @@ class _SwinBlockFn(torch.autograd.Function):
         prompt = ctx.saved_tensors[0] if ctx.has_prompt else None
         dx, dprompt, dts = swin_ops.swin_block_backward(ctx.saved, ctx.w, prompt, dy.contiguous(), need_dx, need_p)
         ctx.saved = None
-        return dx, dprompt, dts, None, None, None, None
+        return dx, dprompt, dts, None, None, None, None, None
 
 
 _SWIN_WG_ORDER = ("ln1_w", "ln1_b", "wq", "wk", "wv", "wproj", "bproj", "ln2_w", "ln2_b", "wmlp", "bmlp")
@@ -241,6 +241,110 @@ class _TokenScoresFn(torch.autograd.Function):
         return dW, dE, None, None
 
 
+class _TokenScoresMultiFn(torch.autograd.Function):
+    """The token scores of several blocks in one launch each way (mivp_token_scores_{fwd,bwd}_multi).  ``meta`` = tuple of
+    (n_prompt, scale) per block; tensors = W_0, E_0, W_1, E_1, ..."""
+
+    @staticmethod
+    def forward(ctx, meta, *WE):
+        n = len(meta)
+        Ws = [WE[2 * i].detach().float().contiguous() for i in range(n)]
+        Es = [WE[2 * i + 1].detach().float().contiguous() for i in range(n)]
+        e = int(Ws[0].shape[1])
+        ts = [torch.empty((Ws[i].shape[0], meta[i][0]), dtype=torch.float32, device=Ws[i].device) for i in range(n)]
+        vp = lambda ts_: (C.c_void_p * n)(*[t.data_ptr() for t in ts_])
+        L.call("mivp_token_scores_fwd_multi", C.c_int32(n), vp(Ws), vp(Es), (C.c_int32 * n)(*[int(w_.shape[0]) for w_ in Ws]),
+               (C.c_int32 * n)(*[m[0] for m in meta]), C.c_int32(e), (C.c_float * n)(*[m[1] for m in meta]), vp(ts), L.stream())
+        ctx.save_for_backward(*Ws, *Es)
+        ctx.meta = meta
+        return tuple(ts)
+
+    @staticmethod
+    def backward(ctx, *dts):
+        meta = ctx.meta
+        n = len(meta)
+        Ws, Es = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        e = int(Ws[0].shape[1])
+        dts = [None if g is None else g.contiguous().float() for g in dts]
+        dW = [torch.empty_like(w_) for w_ in Ws]
+        dE = [torch.zeros_like(E_) if E_.shape[0] != meta[i][0] else torch.empty_like(E_) for i, E_ in enumerate(Es)]
+        vp = lambda ts_: (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts_])
+        L.call("mivp_token_scores_bwd_multi", C.c_int32(n), vp(dts), vp(Ws), vp(Es),
+               (C.c_int32 * n)(*[int(w_.shape[0]) for w_ in Ws]), (C.c_int32 * n)(*[m[0] for m in meta]), C.c_int32(e),
+               (C.c_float * n)(*[m[1] for m in meta]), vp(dW), vp(dE), L.stream())
+        out = [None]
+        for i in range(n):
+            out += [dW[i], dE[i]]
+        return tuple(out)
+
+
+def _block_param_lists(block):
+    pe, attn = block.pe, block.attn
+    body = [block.attn_norm.weight, block.attn_norm.bias, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
+            attn.proj.weight, attn.proj.bias, block.mlp_norm.weight, block.mlp_norm.bias, block.mlp.weight,
+            block.mlp.bias]
+    content = [pe.enc_content_h, pe.enc_content_w, pe.enc_content_d, pe.weights_content_h, pe.weights_content_w,
+               pe.weights_content_d]
+    return body, content
+
+
+def _block_weights(block, device):
+    body, content = _block_param_lists(block)
+
+    def build():
+        sd = {k: v for k, v in block.state_dict().items()}
+        return swin_ops.weights_from_state(sd, "", block.num_heads, block.embed_dim, 0, device, need_bwd=True)
+
+    return block._wcache.get("w", body + content, build)
+
+
+def prepare_prompted_blocks(pairs):
+    """Prompt-side operands of several Swin blocks at once: ``pairs`` = [(block, prompt parameter [Np, C]), ...] in the order the
+    blocks will run.  A prompt-tuning step used to launch token scores, mivp_relbias_aug and mivp_prompt_kv_fwd per prompted
+    block -- three latency-bound 5-8 us kernels -- and the token-score gradient kernel per block on the way back (12 prompted
+    blocks: ~0.4 ms of a 5.5 ms cfg3 step).  Here the token scores of all blocks are one launch each way, prompt K / V of all
+    blocks one launch (which also drops ts into the prompt rows of each block's cached K'-augmentation image), and
+    mivp_relbias_aug leaves the per-step path.  The results are parked on the blocks and picked up by ``swin_block``; blocks
+    with trainable body / bias-table parameters, several prompt slots or CPU tensors are left to the per-block path."""
+    elig = []
+    for blk, prm in pairs:
+        pe = blk.pe
+        if prm is None or prm.dim() != 2 or not prm.is_cuda or not getattr(pe, "use_token_params", False):
+            continue
+        if len(pe.enc_token) != 1 or int(prm.shape[0]) > int(pe.enc_token[0].shape[0]):
+            continue
+        body, content = _block_param_lists(blk)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in body + content):
+            continue
+        elig.append((blk, prm))
+    for c0 in range(0, len(elig), 16):
+        chunk = elig[c0:c0 + 16]
+        if len(chunk) < 2:
+            break
+        n = len(chunk)
+        dev = chunk[0][1].device
+        ws = [_block_weights(blk, dev) for blk, _ in chunk]
+        nps = [int(prm.shape[0]) for _, prm in chunk]
+        descs = [swin_ops.prompt_desc(blk.attn_norm.weight.shape[0], blk.num_heads, blk.window_size, nps[i])
+                 for i, (blk, _) in enumerate(chunk)]
+        meta = tuple((nps[i], float(blk.pe.scale)) for i, (blk, _) in enumerate(chunk))
+        we = []
+        for blk, _ in chunk:
+            we += [blk.pe.weights_token, blk.pe.enc_token[0]]
+        ts = _TokenScoresMultiFn.apply(meta, *we)
+        aug = [swin_ops.prompt_aug_image(ws[i], descs[i]) for i in range(n)]           # cached per weights object
+        prs = [prm.detach().to(torch.float32).contiguous() for _, prm in chunk]
+        kps = [torch.empty((ws[i].heads, descs[i].Npp, descs[i].C // ws[i].heads), dtype=torch.bfloat16, device=dev) for i in range(n)]
+        vps = [torch.empty_like(t) for t in kps]
+        darr = (L.SwinDesc * n)(*descs)
+        vp = lambda ts_: (C.c_void_p * n)(*[t.data_ptr() for t in ts_])
+        L.call("mivp_prompt_kv_fwd_multi", C.c_int32(n), darr, vp(prs), vp([w_.ln1_w for w_ in ws]), vp([w_.ln1_b for w_ in ws]),
+               vp([w_.wqkv for w_ in ws]), vp([t.detach() for t in ts]), vp(kps), vp(vps), vp([a[1] for a in aug]), L.stream())
+        for i, (blk, prm) in enumerate(chunk):
+            key = (int(descs[i].Nqp), int(descs[i].Nkp), int(descs[i].augp), nps[i])
+            blk.__dict__["_pre"] = (prm, ts[i], (key, kps[i], vps[i], aug[i][0], aug[i][1]))
+
+
 def token_scores(pe, n_prompt):
     """Bias of the prompt-token key columns (RelativePE.token_scores) through the fused kernels when the block holds
     one prompt (max_prompts == 1, the reference's configuration); the torch form otherwise."""
@@ -264,24 +368,19 @@ def content_tables(pe):
 
 def swin_block(block, x, prompt: Optional[torch.Tensor]):
     pe, attn = block.pe, block.attn
-    body = [block.attn_norm.weight, block.attn_norm.bias, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
-            attn.proj.weight, attn.proj.bias, block.mlp_norm.weight, block.mlp_norm.bias, block.mlp.weight,
-            block.mlp.bias]
-    content = [pe.enc_content_h, pe.enc_content_w, pe.enc_content_d, pe.weights_content_h, pe.weights_content_w,
-               pe.weights_content_d]
+    body, content = _block_param_lists(block)
     n_prompt = 0 if prompt is None else int(prompt.shape[0])
     train_w = torch.is_grad_enabled() and any(p.requires_grad for p in body + content)
-
-    def build():
-        sd = {k: v for k, v in block.state_dict().items()}
-        return swin_ops.weights_from_state(sd, "", block.num_heads, block.embed_dim, 0, x.device, need_bwd=True)
-
-    w = block._wcache.get("w", body + content, build)
-    ts = None
+    w = _block_weights(block, x.device)
+    parked = block.__dict__.pop("_pre", None)          # prepare_prompted_blocks: (prompt, ts, operands) for this forward
+    ts = pre = None
     if n_prompt:
         if not pe.use_token_params:
             raise RuntimeError("prompt tokens passed to a block built without token bias parameters")
-        ts = token_scores(pe, n_prompt)           # autograd carries d(ts) into weights_token / enc_token
+        if parked is not None and parked[0] is prompt and not train_w:
+            ts, pre = parked[1], parked[2]
+        else:
+            ts = token_scores(pe, n_prompt)       # autograd carries d(ts) into weights_token / enc_token
     dropout = None
     p_attn, p_proj = float(attn.attn_drop.p), float(attn.proj_drop.p)
     if block.training and (p_attn > 0 or p_proj > 0):
@@ -293,7 +392,7 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
         t_h, t_w, t_d = content_tables(pe)        # same for the content tables [heads, 2w-1]
         return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, dropout,
                                        *body)
-    return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size, dropout)
+    return _SwinBlockFn.apply(x, prompt, ts, w, block.window_size, block.shift_size, dropout, pre)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -122,6 +122,44 @@ def make_desc(B, C, heads, tb: BlockTables, n_prompt: int) -> L.SwinDesc:
     return d
 
 
+def prompt_desc(Cc: int, heads: int, window, n_prompt: int) -> L.SwinDesc:
+    """The descriptor fields the prompt-side kernels read (no volume geometry: B = P = 1)."""
+    d = L.SwinDesc()
+    d.B, d.C, d.heads = 1, int(Cc), int(heads)
+    w = [int(v) for v in window]
+    d.P = 1
+    d.Nq = w[0] * w[1] * w[2]
+    d.Nqp = round_up(d.Nq, 16)
+    d.vol_in = d.vol_out = d.Nq
+    d.Np = int(n_prompt)
+    d.Npp = round_up(n_prompt, 16)
+    d.Nkp = round_up(d.Nqp + d.Npp, 32)
+    d.aug = w[0] + w[1] + w[2] - 1
+    d.augp = round_up(d.aug, 4)
+    d.has_mask = 0
+    for a in range(3):
+        d.win[a] = w[a]
+    d.q_scale = float((Cc // heads) ** -0.5)
+    d.ln_eps = 1e-6
+    return d
+
+
+def prompt_aug_image(w: SwinBlockWeights, d: L.SwinDesc):
+    """(qa, ka) of a prompted block for ts = 0, cached on the weights object: with frozen content tables only the prompt
+    rows' i0 columns of ka change from step to step, and mivp_prompt_kv_fwd_multi rewrites those."""
+    key = ("prompt", int(d.Nqp), int(d.Nkp), int(d.augp), int(d.Np))
+    if w.aug_cache is None:
+        w.aug_cache = {}
+    if key not in w.aug_cache:
+        dev = w.t_h.device
+        qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
+        ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
+        zero = torch.zeros((w.heads, d.Np), dtype=torch.float32, device=dev)
+        L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(zero), L.ptr(qa), L.ptr(ka), L.stream())
+        w.aug_cache[key] = (qa, ka)
+    return w.aug_cache[key]
+
+
 @dataclass
 class SwinSaved:
     desc: object
@@ -154,7 +192,7 @@ def set_dropout(d: L.SwinDesc, dropout):
 
 
 def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinBlockWeights,
-                       ts: Optional[torch.Tensor], window, shift_cfg, save: bool = False, dropout=None):
+                       ts: Optional[torch.Tensor], window, shift_cfg, save: bool = False, dropout=None, pre=None):
     """x: bf16 [B, H, W, D, C] channels-last; prompt: f32 [Np, C] or None; ts: f32 [heads, Np] prompt-token
     bias scores (``None`` -> ``w.ts``); dropout: None or (p_attn, p_proj, seed_attn, seed_proj) for a training
     forward with ``attn_drop`` / ``proj_drop`` (window_attention.py:57,60).  Returns y (same shape) and, if
@@ -180,24 +218,29 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     L.call("mivp_swin_qkv_fwd", C.byref(d), L.ptr(x), L.ptr(tb.tok_src), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv_f),
            L.ptr(q), L.ptr(k), L.ptr(v), st)
     kp = vp = None
-    if n_prompt:
-        kp = torch.empty((w.heads, d.Npp, hd), dtype=BF16, device=dev)
-        vp = torch.empty_like(kp)
-        pr = prompt.detach().to(torch.float32).contiguous()
-        L.call("mivp_prompt_kv_fwd", C.byref(d), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
-               L.ptr(kp), L.ptr(vp), L.ptr(None), st)
-    aug_key = (d.Nqp, d.Nkp, d.augp)
-    cached = None if (n_prompt or w.aug_cache is None) else w.aug_cache.get(aug_key)
-    if cached is not None:
-        qa, ka = cached
+    if pre is not None and pre[0] != (int(d.Nqp), int(d.Nkp), int(d.augp), n_prompt):
+        pre = None                               # prepared for another window geometry: recompute here
+    if pre is not None:                          # functional.prepare_prompted_blocks: prompt K / V and the bias columns are ready
+        _, kp, vp, qa, ka = pre
     else:
-        qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
-        ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
-        L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(ts), L.ptr(qa), L.ptr(ka), st)
-        if not n_prompt:                     # without prompt columns the tables depend on the (frozen) weights only
-            if w.aug_cache is None:
-                w.aug_cache = {}
-            w.aug_cache[aug_key] = (qa, ka)
+        if n_prompt:
+            kp = torch.empty((w.heads, d.Npp, hd), dtype=BF16, device=dev)
+            vp = torch.empty_like(kp)
+            pr = prompt.detach().to(torch.float32).contiguous()
+            L.call("mivp_prompt_kv_fwd", C.byref(d), L.ptr(pr), L.ptr(w.ln1_w), L.ptr(w.ln1_b), L.ptr(w.wqkv),
+                   L.ptr(kp), L.ptr(vp), L.ptr(None), st)
+        aug_key = (d.Nqp, d.Nkp, d.augp)
+        cached = None if (n_prompt or w.aug_cache is None) else w.aug_cache.get(aug_key)
+        if cached is not None:
+            qa, ka = cached
+        else:
+            qa = torch.empty((d.Nqp, d.augp), dtype=BF16, device=dev)
+            ka = torch.empty((w.heads, d.Nkp, d.augp), dtype=BF16, device=dev)
+            L.call("mivp_relbias_aug", C.byref(d), L.ptr(w.t_h), L.ptr(w.t_w), L.ptr(w.t_d), L.ptr(ts), L.ptr(qa), L.ptr(ka), st)
+            if not n_prompt:                     # without prompt columns the tables depend on the (frozen) weights only
+                if w.aug_cache is None:
+                    w.aug_cache = {}
+                w.aug_cache[aug_key] = (qa, ka)
     o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
     lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
     fp8 = USE_FP8_ATTN_FWD and hd < 16 and hd + d.augp <= 32 and not dropout

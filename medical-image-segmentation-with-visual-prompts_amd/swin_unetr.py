@@ -457,6 +457,9 @@ class SwinUnetR(nn.Module):
         """Returns channels-last bf16 features, deepest first, input volume last (as the reference's
         ``out_vit`` list, swin_unetr.py:46-63)."""
         feats = [x]
+        if self.conf.use_encoder_prompting:          # prompt-side operands of every encoder block in three launches
+            Fn.prepare_prompted_blocks([(blk, prm) for j in range(self.conf.depth_unet)
+                                        for blk, prm in zip(self.encoder_blocks[j].swin_blocks, self._prompts("enc", j))])
         enc = Fn.patch_embed(self, self.input_layer[0], self.input_layer[1], x)
         feats.insert(0, enc)
         for j in range(self.conf.depth_unet):
@@ -469,6 +472,13 @@ class SwinUnetR(nn.Module):
         low-resolution output, i.e. skips ``output_layer`` (the x2 trilinear upsample)."""
         c = self.conf
         depth = c.depth_unet
+        if c.use_decoder_prompting:                  # ... and of every decoder block
+            pairs = []
+            for j in range(depth):
+                layer = getattr(self.decoder_blocks[j], "swin_layer", None)
+                if layer is not None:
+                    pairs += list(zip(layer.swin_blocks, self._prompts("dec", j)))
+            Fn.prepare_prompted_blocks(pairs)
         if c.unetr_res_block == "full":
             dec = Fn.unetr_basic_block(self, "bottleneck", self.bottleneck, feats[0]) + feats[0]
         else:
