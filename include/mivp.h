@@ -118,6 +118,10 @@ int mivp_prompt_kv_fwd(const MivpSwinDesc* d, const float* prompt, const float* 
 /* prompt-token bias scores and their gradients (relative_positional_encoding.py:128-135):
  *   ts[h][t] = scale * sum_k W[h][k] * E[t][k]   (W = weights_token [heads][e], E = enc_token rows [Np][e], all f32)
  *   dW[h][k] = scale * sum_t dts[h][t] E[t][k],  dE[t][k] = scale * sum_h dts[h][t] W[h][k]                       */
+int mivp_token_scores_fwd(const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale, float* ts,
+                          mivp_stream_t stream);
+int mivp_token_scores_bwd(const float* dts, const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale,
+                          float* dW, float* dE, mivp_stream_t stream);
 /* Batched forms for prompt tuning (n <= 16 blocks per call, arrays of n host-side entries): every one of these kernels lasts
  * 5-10 us whatever it computes, and a step runs one per prompted block.  mivp_prompt_kv_fwd_multi also writes the token bias
  * ts into the prompt rows of each block's K'-augmentation image ka[i] (an image mivp_relbias_aug produced with ts = 0: with
@@ -130,11 +134,6 @@ int mivp_token_scores_bwd_multi(int32_t n, const float* const* dts /* entries ma
 int mivp_prompt_kv_fwd_multi(int32_t n, const MivpSwinDesc* d, const float* const* prompt, const float* const* ln_w,
                              const float* const* ln_b, const void* const* wqkv, const float* const* ts, void* const* kp,
                              void* const* vp, void* const* ka, mivp_stream_t stream);
-
-int mivp_token_scores_fwd(const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale, float* ts,
-                          mivp_stream_t stream);
-int mivp_token_scores_bwd(const float* dts, const float* W, const float* E, int32_t heads, int32_t np, int32_t e, float scale,
-                          float* dW, float* dE, mivp_stream_t stream);
 
 /* relative-position bias as MFMA augmentation dims (relative_positional_encoding.py:99-142)
  *   t_h [heads][2*w0-1], t_w, t_d: per-axis relative tables  T_a[h][j-i+w_a-1] = s/3 * W_a[h] . E_a[...]

@@ -473,3 +473,37 @@ def test_unetr_up_block_option(res_block, unetr_res):
              "seg_pred": torch.randn(batch, conf.output_channels_pretrain, size, size, size, generator=g) / size ** 1.5}
     trainable = OracleSwinUnetR(conf, sd).trainable_keys()
     _check_all_gradients(conf, sd, x, gouts, trainable, 2.5e-2)
+
+
+def test_batched_prompt_operands_equal_the_per_block_path():
+    """functional.prepare_prompted_blocks (token scores and prompt K / V of all prompted blocks in one launch each, cached bias
+    augmentation image with the ts columns rewritten) against the per-block kernels: same arithmetic, so logits and every
+    prompt-side gradient must agree to bf16 rounding of identical values (bitwise for the f32 parameter gradients' inputs)."""
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    from mivp_amd.swin_unetr import SwinUnetR
+    fx = load_fixture("unetr_downstream_e1d1")
+    conf = Namespace(**fx.meta["conf"])
+    sd = round_weights(fx["sd"])
+    x, gout = fx["in"]["x"].to(DEV), fx["in"]["gout"].to(DEV)
+    runs = []
+    for batched in (True, False):
+        model = SwinUnetR(conf)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train()
+        keep = Fn.prepare_prompted_blocks
+        if not batched:
+            Fn.prepare_prompted_blocks = lambda pairs: None
+        try:
+            out = model(x)["downstream"]
+            (out * gout).sum().backward()
+        finally:
+            Fn.prepare_prompted_blocks = keep
+        torch.cuda.synchronize()
+        runs.append((out.detach().float().cpu(), {k: q.grad.detach().cpu() for k, q in model.named_parameters() if q.grad is not None}))
+    (o1, g1), (o2, g2) = runs
+    assert rel_l2(o1, o2) < 1e-6
+    assert sorted(g1) == sorted(g2)
+    for k in g1:
+        if float(g2[k].norm()) > 0:
+            assert rel_l2(g1[k], g2[k]) < 1e-5, (k, rel_l2(g1[k], g2[k]))
