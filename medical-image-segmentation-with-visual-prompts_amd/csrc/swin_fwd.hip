@@ -441,7 +441,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
     // Q' fragments (+ region ids) of a query tile: unconditional loads (common.hpp "Branch-free loads"), issued ONE TILE AHEAD:
     // written as conditional loads in the tile's prologue they were 2-3 dependent memory round trips in front of every
     // ~1 us key loop of the wave.
+    // per-lane piece offsets of query tile 0 and their per-tile strides (the piece's source -- q or the bias one-hots -- is a
+    // lane constant): a tile's addresses are one multiply-add per piece
     const long to_qa = qa - qb;
+    long q_off0[DKS][2];
+    int q_step[DKS][2];
+    bool q_keep[DKS][2];
+#pragma unroll
+    for (int s = 0; s < DKS; ++s)
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c4 = 8 * s + 2 * g + hlf;
+            const int ca = min(max(c4 - hd4, 0), a4 - 1);
+            q_off0[s][hlf] = sel(c4 < hd4, (long)(r * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(r * A + 4 * ca));
+            q_step[s][hlf] = sel(c4 < hd4, 16 * hd, 16 * A);
+            q_keep[s][hlf] = c4 < hd4 + a4;
+        }
     auto load_q = [&](int qt_first, bf16x8 (&qfo)[QT][DKS], uint32_t (&rqo)[QT]) {
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
@@ -452,12 +467,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
             for (int s = 0; s < DKS; ++s) {
                 bf16x4 piece[2];
 #pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int c4 = 8 * s + 2 * g + hlf;
-                    const int ca = min(max(c4 - hd4, 0), a4 - 1);
-                    const long off = sel(c4 < hd4, (long)(row * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(row * A + 4 * ca));
-                    piece[hlf] = keep_if(ld4(qb + off), c4 < hd4 + a4);
-                }
+                for (int hlf = 0; hlf < 2; ++hlf)
+                    piece[hlf] = keep_if(ld4(qb + (q_off0[s][hlf] + (long)(qt * q_step[s][hlf]))), q_keep[s][hlf]);
                 qfo[a][s] = cat44(piece[0], piece[1]);
             }
         }
