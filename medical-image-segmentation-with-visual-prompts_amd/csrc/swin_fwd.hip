@@ -647,20 +647,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
         };
         if (MASKED && cut) walk(std::true_type{}, std::true_type{});
         else walk(std::false_type{}, std::true_type{});
+        float ls_of[QT];
         {
             bool bad = false;
 #pragma unroll
-            for (int a = 0; a < QT; ++a) bad = bad || !(row_sum_of(a) < 1.2676506e30f);       // 2^100; also catches NaN
+            for (int a = 0; a < QT; ++a) { ls_of[a] = row_sum_of(a); bad = bad || !(ls_of[a] < 1.2676506e30f); }      // 2^100; also catches NaN
             if (__any(bad)) {                                // overflow of the optimistic steps: redo the tile with the tested ones
                 reset();
                 if (MASKED && cut) walk(std::true_type{}, std::false_type{});
                 else walk(std::false_type{}, std::false_type{});
+#pragma unroll
+                for (int a = 0; a < QT; ++a) ls_of[a] = row_sum_of(a);
             }
         }
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
             if (a > 0 && qt0 + a >= nqt) continue;
-            const float ls = row_sum_of(a);
+            const float ls = ls_of[a];
             const float inv = (DROP ? d.attn_drop_scale : 1.0f) * __builtin_amdgcn_rcpf(ls);
 #pragma unroll
             for (int dd = 0; dd < DVT; ++dd) {
