@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.0, help="attn_drop = proj_drop (the yml default is 0.1)")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steps before the warm-up (>= 10 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the whole step in a HIP graph and time replays (train.GraphedStep; single process, dropout 0); "
+                         "the roofline kernels are then timed in a few eager steps AFTER the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK)")
@@ -164,6 +167,8 @@ def main():
     from mivp_amd.swin_unetr import SwinUnetR
 
     rank, local, world = train.dist_env()
+    if args.graph and (world > 1 or args.dropout > 0):
+        raise SystemExit("--graph records a single-process step without dropout")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = args.device if args.device >= 0 else local
@@ -187,21 +192,26 @@ def main():
         if world > 1:
             mm.net_student = student
         net = mm
-        opt = train.build_optimizer(mm, conf)
+        opt = train.build_optimizer(mm, conf, capturable=args.graph)
         sched = train.build_scheduler(opt, conf)
-        loss_prt = ClusteredPrototypeLoss(float(conf.reduction_factor), int(conf.k_means_iterations), float(conf.fwhm))
+        loss_prt = ClusteredPrototypeLoss(float(conf.reduction_factor), int(conf.k_means_iterations), float(conf.fwhm),
+                                          static_jitter=args.graph)
         views = ST.synthetic_views(conf, batch, size, dev, rank)
 
-        def one_step():
+        def eager_step():
             return ST.students_teacher_step(mm, opt, sched, loss_prt, conf, views)
+
+        one_step = ST.graphed_students_teacher_step(mm, opt, sched, loss_prt, conf, views) if args.graph else eager_step
     else:
         model = SwinUnetR(conf).to(dev).train()
         net = train.wrap_ddp(model, dev_index, gloo=args.backend == "gloo") if world > 1 else model
-        opt = train.build_optimizer(net, conf)
+        opt = train.build_optimizer(net, conf, capturable=args.graph)
         x, y = train.synthetic_batch(conf, batch, size, dev, rank)
 
-        def one_step():
+        def eager_step():
             return train.train_step(net, opt, conf, x, y)
+
+        one_step = train.graphed_train_step(net, opt, conf, x, y) if args.graph else eager_step
 
     # the largest MFMA-shaped kernel: the last decoder stage's conv_concat (implicit GEMM, K = 27*144, N = 48)
     hc = conf.hidden_channels
@@ -234,6 +244,13 @@ def main():
         loss = one_step()
     sync()
     dt = time.perf_counter() - t0
+    if args.graph:
+        # a replay issues no C-ABI calls from Python, so the per-kernel event pairs have nothing to wrap: the same kernels
+        # are timed in eager steps of the same state, outside the timed region
+        loss = loss.clone()
+        for _ in range(5):
+            eager_step()
+        sync()
     _lib.profile_reset(False)
     dt = train.max_over_ranks(dt, dev if args.backend == "nccl" else None)
     if not torch.isfinite(loss):
@@ -281,7 +298,8 @@ def main():
                                    f"dec_prompt={conf.use_decoder_prompting}, dropout {conf.attn_drop}, random-init weights"
                                    + (", students/teacher step (2 students + EMA teacher, ClusteredPrototypeLoss)" if ssl else ""),
                        "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": float(loss),
-                       "backend": args.backend if world > 1 else None},
+                       "backend": args.backend if world > 1 else None,
+                       "launch": "hip-graph replay (whole step recorded once)" if args.graph else "eager (one C-ABI call per kernel)"},
             "roofline": roof, "roofline_attention": roof_attn,
         }
         if world == 1 and not args.no_cpu_baseline:

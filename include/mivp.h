@@ -545,6 +545,14 @@ int mivp_sample_points_bwd(const float* gout, int32_t B, int32_t H, int32_t W, i
  * index, 1024-element chunk), tensor-major. */
 int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
                      const float* groups, int32_t n_groups, const void* chunks, mivp_stream_t stream);
+/* The same step with the per-group hyper-parameters read from DEVICE memory (groups_dev: [8][8] f32, rows as above): the
+ * form a HIP graph records, so that every replay uses the learning rate (WarmupCosineSchedule, modules/utils.py:67-89) and
+ * bias corrections of its own step.  Bit-equal to mivp_adamw_multi for equal values. */
+int mivp_adamw_multi_dev(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                         const float* groups_dev, int32_t n_groups, const void* chunks, mivp_stream_t stream);
+/* n <= 64 floats from a HOST array into device memory as the arguments of a one-wave kernel (stream-ordered; refreshes the
+ * scalars a recorded graph reads: the optimizer's groups_dev) */
+int mivp_store_floats(float* dst, const float* host_values, int32_t n, mivp_stream_t stream);
 /* EMA teacher update (momentum_model.py:27-36): tensors = device array of {float* teacher, const float* student, int64 n} */
 int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream);
 int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2: EMA record */

@@ -146,12 +146,17 @@ struct AdamGrads { const float* g[ADAM_GRADS_PER_LAUNCH]; };    // gradient poin
 
 constexpr int OPT_CHUNK = 1024;
 
+// DEV: the per-group hyper-parameters come from device memory (``groups_dev``: [8] AdamGroup) instead of the kernel
+// arguments, so that a launch recorded in a HIP graph sees the learning rate and bias corrections of the step it is
+// REPLAYED in (train.GraphedStep refreshes the buffer before every replay).
+template <bool DEV>
 __global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restrict__ tensors, AdamGrads grads, int grad_base,
-                                                     AdamGroups groups, const int2* __restrict__ chunks) {
+                                                     AdamGroups groups, const AdamGroup* __restrict__ groups_dev,
+                                                     const int2* __restrict__ chunks) {
     const int2 ck = chunks[blockIdx.x];
     const AdamTensor t = tensors[ck.x];
     const float* __restrict__ tg = grads.g[ck.x - grad_base];
-    const AdamGroup h = groups.g[t.group];
+    const AdamGroup h = DEV ? groups_dev[t.group] : groups.g[t.group];
     const long base = (long)ck.y * OPT_CHUNK;
     // torch.optim.AdamW (single-tensor formulas, same operation order, so the result is bit-equal on f32):
     //   p *= 1 - lr * wd ; m = m + (g - m) * (1 - b1)  [lerp] ; v = v * b2 + g * g * (1 - b2)
@@ -189,25 +194,58 @@ __global__ __launch_bounds__(256) void k_ema_multi(const EmaTensor* __restrict__
 
 }  // namespace
 
-extern "C" int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
-                                const float* groups, int32_t n_groups, const void* chunks, mivp_stream_t stream) {
-    MIVP_REQUIRE(tensors && grads && groups && chunks && chunk_begin && n_tensors > 0 && n_groups >= 1 && n_groups <= 8);
+static int adamw_launch(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                        const float* groups_host, const float* groups_dev, int32_t n_groups, const void* chunks,
+                        mivp_stream_t stream) {
     AdamGroups gs;
     for (int i = 0; i < 8; ++i) {
-        const float* src = groups + 8 * (i < n_groups ? i : 0);
-        gs.g[i] = AdamGroup{src[0], src[1], src[2], src[3], src[4], src[5], src[6], 0.f};
+        const float* src = groups_host ? groups_host + 8 * (i < n_groups ? i : 0) : nullptr;
+        gs.g[i] = src ? AdamGroup{src[0], src[1], src[2], src[3], src[4], src[5], src[6], 0.f} : AdamGroup{};
     }
-    // gradient pointers and hyper-parameters travel as kernel arguments (HOST arrays here): nothing is uploaded per step
+    // gradient pointers (and, in the plain form, the hyper-parameters) travel as kernel arguments: nothing is uploaded per step
     for (int base = 0; base < n_tensors; base += ADAM_GRADS_PER_LAUNCH) {
         const int cnt = n_tensors - base < ADAM_GRADS_PER_LAUNCH ? n_tensors - base : ADAM_GRADS_PER_LAUNCH;
         AdamGrads gp;
         for (int i = 0; i < ADAM_GRADS_PER_LAUNCH; ++i) gp.g[i] = (const float*)grads[base + (i < cnt ? i : 0)];
         const int c0 = chunk_begin[base], c1 = chunk_begin[base + cnt];
         if (c1 <= c0) continue;
-        hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)tensors,
-                           gp, base, gs, (const int2*)chunks + c0);
+        if (groups_dev)
+            hipLaunchKernelGGL(k_adamw_multi<true>, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream,
+                               (const AdamTensor*)tensors, gp, base, gs, (const AdamGroup*)groups_dev, (const int2*)chunks + c0);
+        else
+            hipLaunchKernelGGL(k_adamw_multi<false>, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream,
+                               (const AdamTensor*)tensors, gp, base, gs, (const AdamGroup*)nullptr, (const int2*)chunks + c0);
     }
     return mivp_check_launch("adamw_multi");
+}
+
+extern "C" int mivp_adamw_multi(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                                const float* groups, int32_t n_groups, const void* chunks, mivp_stream_t stream) {
+    MIVP_REQUIRE(tensors && grads && groups && chunks && chunk_begin && n_tensors > 0 && n_groups >= 1 && n_groups <= 8);
+    return adamw_launch(tensors, grads, n_tensors, chunk_begin, groups, nullptr, n_groups, chunks, stream);
+}
+
+extern "C" int mivp_adamw_multi_dev(const void* tensors, const void* const* grads, int32_t n_tensors, const int32_t* chunk_begin,
+                                    const float* groups_dev, int32_t n_groups, const void* chunks, mivp_stream_t stream) {
+    MIVP_REQUIRE(tensors && grads && groups_dev && chunks && chunk_begin && n_tensors > 0 && n_groups >= 1 && n_groups <= 8);
+    return adamw_launch(tensors, grads, n_tensors, chunk_begin, nullptr, groups_dev, n_groups, chunks, stream);
+}
+
+// up to 64 floats from the HOST into device memory as kernel arguments of a one-wave launch: stream-ordered, no pinned
+// staging buffer whose reuse would have to be fenced (the per-replay refresh of a graph's scalars)
+namespace {
+struct FloatPack { float v[64]; };
+__global__ void k_store_floats(float* __restrict__ dst, FloatPack vals, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+}  // namespace
+
+extern "C" int mivp_store_floats(float* dst, const float* host_values, int32_t n, mivp_stream_t stream) {
+    MIVP_REQUIRE(dst && host_values && n > 0 && n <= 64);
+    FloatPack pk;
+    for (int i = 0; i < 64; ++i) pk.v[i] = i < n ? host_values[i] : 0.f;
+    hipLaunchKernelGGL(k_store_floats, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, pk, (int)n);
+    return mivp_check_launch("store_floats");
 }
 
 extern "C" int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream) {

@@ -394,6 +394,9 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
     if block.training and (p_attn > 0 or p_proj > 0):
         # counter-hash dropout inside the kernels; the two seeds come from torch's CPU generator, so
         # torch.manual_seed() reproduces a run (the random STREAM differs from nn.Dropout's by construction)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attention / projection dropout draws its seeds on the host per call: a recorded graph would "
+                               "replay ONE mask for ever -- train.GraphedStep needs attn_drop = proj_drop = 0")
         seeds = torch.randint(0, 2 ** 31 - 1, (2,))
         dropout = (p_attn, p_proj, int(seeds[0]), int(seeds[1]))
     if train_w:

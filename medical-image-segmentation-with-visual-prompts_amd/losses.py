@@ -27,8 +27,8 @@ def reduced_size(dims: Sequence[int], reduction_factor: float) -> List[int]:
     return [max(int(n // reduction_factor), 1) for n in dims]
 
 
-@lru_cache(maxsize=512)
-def _axis_tables(n_full: int, lo_crop: int, n_crop: int, n_out: int, device_str: str):
+@lru_cache(maxsize=2048)
+def _axis_np(n_full: int, lo_crop: int, n_crop: int, n_out: int):
     """Interpolation taps of one axis: forward (lo, hi, w) per output index (absolute voxel coordinates) and backward
     (i1, w1, i2, w2) per voxel coordinate.  Sample i sits at x = ((2 i + 1) n_crop / n_out - 1) / 2 of the cropped axis
     (grid_sample with align_corners = False on an identity grid)."""
@@ -55,8 +55,64 @@ def _axis_tables(n_full: int, lo_crop: int, n_crop: int, n_out: int, device_str:
         lo[i], hi[i], w[i] = lo_crop + l, lo_crop + h, ww
         add(lo_crop + l, i, float(np.float32(1.0) - ww))
         add(lo_crop + h, i, float(ww))
+    return lo, hi, w, i1, w1, i2, w2
+
+
+@lru_cache(maxsize=512)
+def _axis_tables(n_full: int, lo_crop: int, n_crop: int, n_out: int, device_str: str):
     dev = torch.device(device_str)
-    return tuple(torch.from_numpy(a).to(dev) for a in (lo, hi, w, i1, w1, i2, w2))
+    return tuple(torch.from_numpy(a).to(dev) for a in _axis_np(n_full, lo_crop, n_crop, n_out))
+
+
+@lru_cache(maxsize=2048)
+def _axis_packed_pinned(n_full: int, lo_crop: int, n_crop: int, n_out: int):
+    """The seven tables of one axis as ONE pinned 4-byte-word buffer [3 n_out + 4 n_full] (lo | hi | w | i1 | w1 | i2 | w2):
+    the source of a JitterSlot refresh (one asynchronous copy per axis; the buffer is never written again)."""
+    words = np.concatenate([a.view(np.int32) for a in _axis_np(n_full, lo_crop, n_crop, n_out)])
+    return torch.from_numpy(words).pin_memory()
+
+
+class JitterSlot:
+    """Persistent device tables of ONE student's jittered sampling grid.  ``_SamplePointsFn`` normally takes its tables from
+    a cache keyed by the jitter, i.e. the table POINTERS change with the jitter; a recorded graph holds pointers, so in
+    graph mode (``ClusteredPrototypeLoss(static_jitter=True)``) the kernels read these fixed buffers and a new jitter is
+    a refresh of their CONTENT (``load``, three small host-to-device copies, stream-ordered before the replay)."""
+
+    def __init__(self):
+        self.geo = None
+        self.bufs = None
+
+    def load(self, dims, out_dims, jitter, device):
+        geo = (tuple(int(v) for v in dims), tuple(int(v) for v in out_dims), str(device))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.geo != geo:
+            if capturing:
+                raise RuntimeError("JitterSlot: the sampling geometry changed between the eager warm-up and the recording")
+            self.bufs = [torch.zeros(3 * od + 4 * n, dtype=torch.int32, device=device) for n, od in zip(geo[0], geo[1])]
+            self.geo = geo
+        if capturing:
+            return                                              # a recording must not freeze today's content into the graph
+        j = [int(v) for v in jitter] if jitter is not None else [0] * 6
+        for a, (n, od) in enumerate(zip(geo[0], geo[1])):
+            lo, nc = j[2 * a], n - j[2 * a] - j[2 * a + 1]
+            if nc < 1:
+                raise ValueError("jitter crop leaves an empty volume")
+            self.bufs[a].copy_(_axis_packed_pinned(n, lo, nc, od), non_blocking=True)
+
+    def reload(self, jitter):
+        if self.geo is None:
+            raise RuntimeError("JitterSlot.reload before the first load")
+        self.load(self.geo[0], self.geo[1], jitter, torch.device(self.geo[2]))
+
+    def tables(self, dims, out_dims):
+        if self.geo is None or self.geo[0] != tuple(int(v) for v in dims) or self.geo[1] != tuple(int(v) for v in out_dims):
+            raise RuntimeError("JitterSlot: volume / grid size differs from the loaded tables")
+        out = []
+        for buf, n, od in zip(self.bufs, self.geo[0], self.geo[1]):
+            f = buf.view(torch.float32)
+            out.append((buf[:od], buf[od:2 * od], f[2 * od:3 * od], buf[3 * od:3 * od + n], f[3 * od + n:3 * od + 2 * n],
+                        buf[3 * od + 2 * n:3 * od + 3 * n], f[3 * od + 3 * n:3 * od + 4 * n]))
+        return out
 
 
 def _ptr3(ts, ctype):
@@ -68,13 +124,16 @@ class _SamplePointsFn(torch.autograd.Function):
     tensor) -> f32 [B, N, C] at the reduced grid's cell centres of the (jitter-cropped) volume."""
 
     @staticmethod
-    def forward(ctx, vol, out_dims, jitter):
+    def forward(ctx, vol, out_dims, jitter, slot=None):
         B, Cc, H, W, D = vol.shape
-        j = [int(v) for v in jitter] if jitter is not None else [0] * 6
-        crop = [(j[0], H - j[0] - j[1]), (j[2], W - j[2] - j[3]), (j[4], D - j[4] - j[5])]
-        if min(c[1] for c in crop) < 1:
-            raise ValueError("jitter crop leaves an empty volume")
-        tabs = [_axis_tables(n, lo, nc, int(od), str(vol.device)) for n, (lo, nc), od in zip((H, W, D), crop, out_dims)]
+        if slot is not None:
+            tabs = slot.tables((H, W, D), out_dims)             # content = the jitter last loaded into the slot
+        else:
+            j = [int(v) for v in jitter] if jitter is not None else [0] * 6
+            crop = [(j[0], H - j[0] - j[1]), (j[2], W - j[2] - j[3]), (j[4], D - j[4] - j[5])]
+            if min(c[1] for c in crop) < 1:
+                raise ValueError("jitter crop leaves an empty volume")
+            tabs = [_axis_tables(n, lo, nc, int(od), str(vol.device)) for n, (lo, nc), od in zip((H, W, D), crop, out_dims)]
         base = vol.permute(0, 2, 3, 4, 1)
         if base.is_contiguous():
             src, clast = base, 1
@@ -107,13 +166,13 @@ class _SamplePointsFn(torch.autograd.Function):
                C.c_int32(Cc), od, _ptr3([t[3] for t in tabs], C.c_int32), _ptr3([t[5] for t in tabs], C.c_int32),
                _ptr3([t[4] for t in tabs], C.c_float), _ptr3([t[6] for t in tabs], C.c_float), L.ptr(g), L.stream())
         g = g.permute(0, 4, 1, 2, 3)                            # channels-first view, like the forward's input
-        return (g if dtype == torch.bfloat16 else g.float()), None, None
+        return (g if dtype == torch.bfloat16 else g.float()), None, None, None
 
 
-def sample_points(vol: torch.Tensor, out_dims: Sequence[int], jitter=None) -> torch.Tensor:
+def sample_points(vol: torch.Tensor, out_dims: Sequence[int], jitter=None, slot: Optional["JitterSlot"] = None) -> torch.Tensor:
     if not vol.is_cuda:
         raise RuntimeError("mivp_amd.losses runs on the GPU only (the CPU oracle lives in oracle/proto_ref.py)")
-    return _SamplePointsFn.apply(vol, tuple(int(v) for v in out_dims), None if jitter is None else tuple(int(v) for v in jitter))
+    return _SamplePointsFn.apply(vol, tuple(int(v) for v in out_dims), None if jitter is None else tuple(int(v) for v in jitter), slot)
 
 
 def _pair_dist(cx: torch.Tensor, cy: torch.Tensor) -> torch.Tensor:
@@ -130,12 +189,24 @@ class ClusteredPrototypeLoss(torch.nn.Module):
     gradients (students_teacher.py:150-207, momentum_model.py:24) -- student gradients and the loss value are identical."""
 
     def __init__(self, reduction_factor: float = 8.0, k_means_iterations: int = 3, fwhm: float = 128.0,
-                 detach_teacher: bool = True):
+                 detach_teacher: bool = True, static_jitter: bool = False):
         super().__init__()
         self.reduction_factor = reduction_factor
         self.k_means_iterations = k_means_iterations
         self.fwhm = fwhm
         self.detach_teacher = detach_teacher
+        # graph mode (train.GraphedStep): the students' sampling tables live in fixed buffers (JitterSlot)
+        self.static_jitter = static_jitter
+        self._slots: List[JitterSlot] = []
+
+    def draw_jitters(self, n_students: int):
+        """The reference's draw (clustered_prototype_loss.py:173-178): six integers per student from the global CPU generator."""
+        return [torch.randint(low=0, high=int(math.ceil(self.reduction_factor)), size=(6,)).tolist() for _ in range(n_students)]
+
+    def load_jitters(self, jitters):
+        """Graph mode: refresh the recorded step's sampling tables (call before each replay)."""
+        for slot, j in zip(self._slots, jitters):
+            slot.reload(j)
 
     def forward(self, emb_s: List[torch.Tensor], emb_t: torch.Tensor, coord_s: List[torch.Tensor], coord_t: torch.Tensor,
                 temp_s: float = 0.066, temp_t: float = 0.033, jitters: Optional[List[Sequence[int]]] = None,
@@ -143,7 +214,7 @@ class ClusteredPrototypeLoss(torch.nn.Module):
         rf = self.reduction_factor
         sigma2 = (self.fwhm / 2.355) ** 2
         if jitters is None:
-            jitters = [torch.randint(low=0, high=int(math.ceil(rf)), size=(6,)).tolist() for _ in emb_s]
+            jitters = self.draw_jitters(len(emb_s))
         if self.detach_teacher:
             emb_t = emb_t.detach()
         rs_t = reduced_size(emb_t.shape[2:], rf)
@@ -169,8 +240,14 @@ class ClusteredPrototypeLoss(torch.nn.Module):
         total = torch.zeros((), dtype=torch.float32, device=emb_t.device)
         for i in range(len(emb_s)):
             rs_s = reduced_size(emb_s[i].shape[2:], rf)
-            e_z = sample_points(emb_s[i], rs_s, jitters[i])
-            c_z = sample_points(coord_s[i].float(), rs_s, jitters[i])
+            slot = None
+            if self.static_jitter:
+                while len(self._slots) <= i:
+                    self._slots.append(JitterSlot())
+                slot = self._slots[i]
+                slot.load(emb_s[i].shape[2:], rs_s, jitters[i], emb_s[i].device)
+            e_z = sample_points(emb_s[i], rs_s, jitters[i], slot)
+            c_z = sample_points(coord_s[i].float(), rs_s, jitters[i], slot)
             dmin, idx = _pair_dist(c_z, c_t).min(dim=-1)
             keep = (dmin <= max_dist).float()
             sim = torch.softmax(F.normalize(e_z, dim=-1) @ e_p_n.transpose(1, 2) / temp_s, dim=-1)

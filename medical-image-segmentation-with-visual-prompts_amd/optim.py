@@ -36,13 +36,21 @@ def _chunk_table(sizes: List[int], device, with_begin: bool = False):
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """``capturable=True``: the launch reads lr / weight decay / bias corrections from a device buffer that ``step()``
+    refreshes with one tiny stream-ordered launch (``mivp_store_floats``) -- the form ``train.GraphedStep`` records.  While
+    the stream is being captured ``step()`` only records the update launch; every replay is preceded by ``advance()``,
+    which does the host side of a step (step counts, this step's hyper-parameters into the device buffer)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) > 8:
             raise ValueError("FusedAdamW supports up to 8 parameter groups")
         self._plan = None
         self._steps = {}          # id(param) -> step count as a Python int (the state's ``step`` tensors are synced lazily)
+        self.capturable = bool(capturable)
+        self._hyper_dev = None
+        self._graph_params = None  # the parameters that had gradients when a graph was recorded (they step on every replay)
 
     def state_dict(self):
         for group in self.param_groups:
@@ -69,6 +77,40 @@ class FusedAdamW(torch.optim.Optimizer):
             "tensors": torch.from_numpy(rows).to(dev), "chunks": chunks, "begin": begin,
         }
 
+    def _hyper(self, stepping):
+        """Advance the step counts of ``stepping`` (ids of the parameters that step now) and return this step's
+        [groups][8] table: lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 0."""
+        hyper = np.zeros((len(self.param_groups), 8), np.float32)
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            step_no = None
+            for p in group["params"]:
+                if id(p) not in stepping:
+                    continue
+                n = self._steps.get(id(p), 0) + 1
+                self._steps[id(p)] = n
+                step_no = float(n)
+            if step_no is None:
+                step_no = 1.0
+            # all parameters of a group that receive gradients step together (as in the reference's trainers)
+            hyper[gi] = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** step_no,
+                         math.sqrt(1.0 - b2 ** step_no), 0.0)
+        return hyper
+
+    def _upload(self, hyper, device):
+        if self._hyper_dev is None or self._hyper_dev.device != device:
+            self._hyper_dev = torch.zeros(64, dtype=torch.float32, device=device)
+        flat = np.ascontiguousarray(hyper.reshape(-1))
+        L.call("mivp_store_floats", L.ptr(self._hyper_dev), flat.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(flat.size), L.stream())
+
+    @torch.no_grad()
+    def advance(self):
+        """Host side of one REPLAYED step (the recorded graph holds the update launch itself)."""
+        if self._graph_params is None:
+            raise RuntimeError("FusedAdamW.advance(): no step has been recorded in a graph")
+        dev = self._hyper_dev.device
+        self._upload(self._hyper(self._graph_params), dev)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -76,10 +118,7 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         entries = []
-        hyper = np.zeros((len(self.param_groups), 8), np.float32)
         for gi, group in enumerate(self.param_groups):
-            b1, b2 = group["betas"]
-            step_no = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -90,19 +129,25 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                n = self._steps.get(id(p), 0) + 1
-                self._steps[id(p)] = n
-                step_no = float(n)
                 entries.append((gi, p, st))
-            if step_no is None:
-                step_no = 1.0
-            # all parameters of a group that receive gradients step together (as in the reference's trainers)
-            hyper[gi] = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** step_no,
-                         math.sqrt(1.0 - b2 ** step_no), 0.0)
         if not entries:
             return loss
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and not self.capturable:
+            raise RuntimeError("FusedAdamW: build the optimizer with capturable=True to record its step in a graph")
+        stepping = {id(p) for _, p, _ in entries}
+        if capturing:
+            # the recording is not a step: counts and the device table are advanced by advance() before each replay
+            hyper = None
+            self._graph_params = stepping
+            if self._hyper_dev is None:
+                raise RuntimeError("FusedAdamW: run at least one eager step before recording (state and tables are built there)")
+        else:
+            hyper = self._hyper(stepping)
         key = tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr()) for _, p, st in entries)
         if self._plan is None or self._plan["key"] != key:
+            if capturing:
+                raise RuntimeError("FusedAdamW: the parameter set changed between the eager warm-up and the recording")
             self._build(entries)
         plan = self._plan
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for _, p, _ in entries]
@@ -112,9 +157,16 @@ class FusedAdamW(torch.optim.Optimizer):
         # the gradient tensors are new every backward (zero_grad(set_to_none=True)): their pointers go to the kernel as
         # arguments (a host array here) -- an upload per step would be a synchronous pageable copy that stalls the launch queue
         gptr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        L.call("mivp_adamw_multi", L.ptr(plan["tensors"]), gptr, C.c_int32(len(grads)),
-               plan["begin"].ctypes.data_as(C.POINTER(C.c_int32)), hyper.ctypes.data_as(C.POINTER(C.c_float)),
-               C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), L.stream())
+        if self.capturable:
+            if hyper is not None:
+                self._upload(hyper, entries[0][1].device)
+            L.call("mivp_adamw_multi_dev", L.ptr(plan["tensors"]), gptr, C.c_int32(len(grads)),
+                   plan["begin"].ctypes.data_as(C.POINTER(C.c_int32)), L.ptr(self._hyper_dev),
+                   C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), L.stream())
+        else:
+            L.call("mivp_adamw_multi", L.ptr(plan["tensors"]), gptr, C.c_int32(len(grads)),
+                   plan["begin"].ctypes.data_as(C.POINTER(C.c_int32)), hyper.ctypes.data_as(C.POINTER(C.c_float)),
+                   C.c_int32(len(self.param_groups)), L.ptr(plan["chunks"]), L.stream())
         return loss
 
 

@@ -95,3 +95,27 @@ def students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: 
     if scheduler is not None:
         scheduler.step()
     return total.detach()
+
+
+def graphed_students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: ClusteredPrototypeLoss, conf: Namespace,
+                                  batch: dict, jitters=None, warmup: int = 2):
+    """``students_teacher_step`` recorded in a HIP graph (train.GraphedStep): EMA update, three forwards, prototype loss,
+    backward and the optimizer launch replay as one launch; per replay the host draws the students' jitter like the
+    reference (``loss_prt.draw_jitters``, or ``jitters()`` if given: a callable returning one list per student), refreshes the
+    sampling tables, advances the optimizer's step counts / hyper-parameters and steps the scheduler.  ``batch`` holds the
+    fixed input tensors.  ``loss_prt`` must have been built with ``static_jitter=True``."""
+    from . import train
+    if not loss_prt.static_jitter:
+        raise ValueError("graph mode needs ClusteredPrototypeLoss(static_jitter=True)")
+    n_st = len(batch["image_st"])
+    state = {"j": None}
+
+    def refresh():
+        state["j"] = jitters() if jitters is not None else loss_prt.draw_jitters(n_st)
+        if loss_prt._slots:                                    # (the first eager warm-up step creates and loads the slots itself)
+            loss_prt.load_jitters(state["j"])
+
+    def body():
+        return students_teacher_step(model, optimizer, None, loss_prt, conf, batch, jitters=state["j"])
+
+    return train.GraphedStep(body, optimizer, scheduler, refresh, warmup)

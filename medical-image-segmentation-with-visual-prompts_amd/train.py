@@ -126,7 +126,7 @@ def dice_focal_loss(logits: torch.Tensor, target: torch.Tensor, include_backgrou
     return dice + focal
 
 
-def build_optimizer(model, conf: Namespace):
+def build_optimizer(model, conf: Namespace, capturable: bool = False):
     """AdamW over the reference's parameter partition for the mode: ``named_parameters_downstream()`` for
     ``downstream`` (segmentation.py:25-39); decoder(+encoder) and prompt-token groups with their own lr /
     weight decay for the ``*_all`` / ``*_decoder`` modes (students_teacher.py:25-68)."""
@@ -136,7 +136,7 @@ def build_optimizer(model, conf: Namespace):
     mode = conf.training_mode
     if mode == "downstream":
         params = [p for _, p in core.named_parameters_downstream()]
-        return FusedAdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream))
+        return FusedAdamW(params, lr=float(conf.lr_downstream), weight_decay=float(conf.weight_decay_downstream), capturable=capturable)
     lr, wd = float(conf.lr_students_teacher), float(conf.weight_decay_students_teacher)
     groups = []
     if mode in ("self_supervised_learning_all", "supervised_learning_all"):
@@ -152,7 +152,7 @@ def build_optimizer(model, conf: Namespace):
     if conf.use_decoder_prompting:
         groups.append({"params": [p for _, p in core.named_parameters_prompt_tokens_decoder()],
                        "lr": float(conf.lr_prompt_tokens), "weight_decay": float(conf.weight_decay_prompt_tokens)})
-    return FusedAdamW(groups, lr=lr, weight_decay=wd)
+    return FusedAdamW(groups, lr=lr, weight_decay=wd, capturable=capturable)
 
 
 def build_scheduler(opt, conf: Namespace):
@@ -185,6 +185,74 @@ def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
     loss.backward()
     opt.step()
     return loss.detach()
+
+
+class GraphedStep:
+    """One whole training step -- forward, loss, backward, optimizer launch -- recorded ONCE in a HIP graph and replayed.
+
+    An eager step is ~85 (cfg1) to ~1700 (cfg0: two students + teacher on 32^3 volumes) launches issued from Python at
+    10-15 us each; where the kernels are shorter than that (cfg0) the step is bound by the host.  A replay is one launch.
+
+    ``body()`` runs the device side of a step on the current stream and returns the loss tensor: model forward, loss,
+    ``optimizer.zero_grad(set_to_none=True)``, ``backward()``, ``optimizer.step()`` -- no scheduler (host arithmetic on
+    ``param_groups``: it runs after every replay here), no ``.item()``.  Its inputs are fixed tensors: feed a new batch by
+    copying into them (``x.copy_(new)``) before the call.  What changes per step on the host side travels through device
+    memory: the optimizer's lr / bias corrections (``FusedAdamW(capturable=True).advance()``) and whatever ``refresh()`` loads
+    (the prototype loss's jitter tables).  Not recordable, and refused: attention / projection dropout (host-drawn seeds),
+    DistributedDataParallel (the bucket all-reduces belong to another stream).
+
+    After a replay the packed-weight caches are marked stale, so an eager forward / evaluation between replays sees the
+    current parameters."""
+
+    def __init__(self, body, optimizer, scheduler=None, refresh=None, warmup: int = 2):
+        from . import functional as Fn
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedStep needs FusedAdamW(capturable=True) (train.build_optimizer(..., capturable=True))")
+        self._fn = Fn
+        self.optimizer, self.scheduler, self.refresh = optimizer, scheduler, refresh
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                      # eager: optimizer state, tables and caches come to life here
+                if refresh is not None:
+                    refresh()
+                body()
+                if scheduler is not None:
+                    scheduler.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)                    # the recorded backward allocates the gradients in the graph's pool
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+        self.launches_eager = None
+
+    def __call__(self) -> torch.Tensor:
+        if self.refresh is not None:
+            self.refresh()
+        self.optimizer.advance()
+        self.graph.replay()
+        self._fn.invalidate_weight_caches()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return self.loss
+
+
+def graphed_train_step(model, opt, conf: Namespace, x, y, warmup: int = 2) -> GraphedStep:
+    """``train_step`` as a recorded graph: call the result with no arguments; ``x`` / ``y`` are its fixed input tensors."""
+    if hasattr(model, "module"):
+        raise ValueError("GraphedStep records a single-process step (no DistributedDataParallel)")
+
+    def body():
+        out = model(x)
+        loss = step_loss(out, conf, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    return GraphedStep(body, opt, None, None, warmup)
 
 
 def dist_env():

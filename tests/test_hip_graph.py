@@ -1,0 +1,132 @@
+"""GPU tests of the recorded-step mode (mivp_amd.train.GraphedStep): a HIP graph of forward + loss + backward + optimizer
+launch, replayed, must leave the SAME bits in every parameter, buffer and optimizer state as the eager step -- the kernels
+are the same kernels in the same order; what differs is who issues them.  What changes per step on the host side
+(learning rate and AdamW bias corrections, the prototype loss's jitter) reaches the replay through device memory."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _same_bits(a, b):
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    return bad
+
+
+def test_capturable_adamw_is_bit_equal_to_the_plain_launch():
+    """FusedAdamW(capturable=True) reads lr / bias corrections from device memory (mivp_adamw_multi_dev); the plain form
+    takes them as kernel arguments: same arithmetic, same bits, schedules included."""
+    import mivp_amd  # noqa: F401
+    from mivp_amd.optim import FusedAdamW, WarmupCosineSchedule
+    g = torch.Generator().manual_seed(3)
+    shapes = [(48, 48), (1030,), (3, 5, 7, 2), (2, 1024)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(q.detach().clone()) for q in pa]
+    grp = lambda ps: [{"params": ps[:2], "lr": 5e-3, "weight_decay": 0.1}, {"params": ps[2:], "lr": 1e-2, "weight_decay": 0.0}]
+    oa, ob = FusedAdamW(grp(pa)), FusedAdamW(grp(pb), capturable=True)
+    sa, sb = WarmupCosineSchedule(oa, 2, 12), WarmupCosineSchedule(ob, 2, 12)
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    assert oa.state_dict()["state"][0]["step"] == ob.state_dict()["state"][0]["step"] == 6
+
+
+@pytest.mark.parametrize("workload", ["tiny", "sup_all_small"])
+def test_graphed_train_step_equals_the_eager_step(workload):
+    """Six steps of the single-network trainer on a small volume: eager vs (two eager warm-up steps + four replays)."""
+    import mivp_amd  # noqa: F401
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    if workload == "tiny":
+        conf, size, batch = train.make_conf("tiny")
+    else:                                                       # every parameter trains (weight-gradient kernels of all blocks)
+        conf, size, batch = train.make_conf("sup_all")
+        size, batch = 32, 2
+    torch.manual_seed(5)
+    ref = SwinUnetR(conf).to(DEV).train()
+    own = copy.deepcopy(ref)
+    x, y = train.synthetic_batch(conf, batch, size, DEV)
+    o_ref = train.build_optimizer(ref, conf)
+    o_own = train.build_optimizer(own, conf, capturable=True)
+    losses_ref = [float(train.train_step(ref, o_ref, conf, x, y)) for _ in range(6)]
+    step = train.graphed_train_step(own, o_own, conf, x, y, warmup=2)
+    losses_own = [float(step()) for _ in range(4)]
+    torch.cuda.synchronize()
+    print(f"[graph {workload}] eager losses {losses_ref[2:]}, replayed {losses_own}")
+    assert losses_own == losses_ref[2:]
+    assert _same_bits(dict(ref.state_dict()), dict(own.state_dict())) == []
+    sa, sb = o_ref.state_dict()["state"], o_own.state_dict()["state"]
+    assert all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
+               and float(sa[k]["step"]) == float(sb[k]["step"]) == 6 for k in sa)
+    # an eager forward between replays sees the replayed parameters (the packed-weight caches were marked stale)
+    own.eval(); ref.eval()
+    with torch.no_grad():
+        key = "downstream" if conf.training_mode == "downstream" else "seg_pred"
+        assert torch.equal(own(x)[key], ref(x)[key])
+    # a new batch is a copy into the recorded input tensors
+    own.train(); ref.train()
+    x2, y2 = train.synthetic_batch(conf, batch, size, DEV, rank=1)
+    x.copy_(x2); y.copy_(y2)
+    l_own = float(step())
+    l_ref = float(train.train_step(ref, o_ref, conf, x, y))
+    assert l_own == l_ref
+    assert _same_bits(dict(ref.state_dict()), dict(own.state_dict())) == []
+
+
+def test_graphed_students_teacher_step_equals_the_eager_step():
+    """configs[0] (two students 32^3 / 24^3 + EMA teacher, prototype loss, AdamW with two groups under the warm-up schedule):
+    five steps with a different jitter each -- eager vs (two warm-up steps + three replays); the jitter reaches the replay as
+    table CONTENT (losses.JitterSlot), lr and bias corrections through the optimizer's device table."""
+    import mivp_amd  # noqa: F401
+    from mivp_amd import train, students_teacher as ST
+    from mivp_amd.losses import ClusteredPrototypeLoss
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, size, batch = train.make_conf("cfg0")
+    conf.warmup_steps_students_teacher = 3                      # the learning rate moves every step
+    torch.manual_seed(9)
+    ref = ST.MomentumModel(conf, SwinUnetR).to(DEV).train()
+    ref.copy_state_dict()
+    own = copy.deepcopy(ref)
+    views = ST.synthetic_views(conf, batch, size, DEV, student_sizes=[32, 24])
+    jit = [[[1, 0, 2, 1, 0, 3], [0, 2, 1, 1, 3, 0]], [[0, 0, 0, 0, 0, 0], [3, 3, 3, 3, 3, 3]], [[2, 1, 0, 3, 1, 2], [1, 1, 2, 0, 0, 1]],
+           [[3, 0, 0, 2, 2, 1], [0, 0, 1, 3, 2, 2]], [[1, 1, 1, 1, 1, 1], [2, 0, 3, 1, 0, 2]]]
+    mk = lambda static: ClusteredPrototypeLoss(float(conf.reduction_factor), int(conf.k_means_iterations), float(conf.fwhm),
+                                               static_jitter=static)
+    o_ref = train.build_optimizer(ref, conf)
+    s_ref = train.build_scheduler(o_ref, conf)
+    l_ref = [float(ST.students_teacher_step(ref, o_ref, s_ref, mk(False), conf, views, jitters=j)) for j in jit]
+    o_own = train.build_optimizer(own, conf, capturable=True)
+    s_own = train.build_scheduler(o_own, conf)
+    feed = iter(jit)
+    step = ST.graphed_students_teacher_step(own, o_own, s_own, mk(True), conf, views, jitters=lambda: next(feed), warmup=2)
+    l_own = [float(step()) for _ in range(3)]
+    torch.cuda.synchronize()
+    print(f"[graph cfg0] eager losses {l_ref[2:]}, replayed {l_own}")
+    assert l_own == l_ref[2:]
+    assert o_own.param_groups[0]["lr"] == o_ref.param_groups[0]["lr"]
+    assert _same_bits(dict(ref.state_dict()), dict(own.state_dict())) == []
+
+
+def test_recording_refuses_dropout_and_plain_optimizers():
+    import mivp_amd  # noqa: F401
+    from mivp_amd import train
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, size, batch = train.make_conf("tiny", dropout=0.1)
+    model = SwinUnetR(conf).to(DEV).train()
+    x, y = train.synthetic_batch(conf, batch, size, DEV)
+    with pytest.raises(ValueError, match="capturable"):
+        train.graphed_train_step(model, train.build_optimizer(model, conf), conf, x, y)
+    with pytest.raises(RuntimeError, match="dropout"):
+        train.graphed_train_step(model, train.build_optimizer(model, conf, capturable=True), conf, x, y)
+    torch.cuda.synchronize()
+    # the failed recording left the process usable
+    conf0, _, _ = train.make_conf("tiny")
+    m0 = SwinUnetR(conf0).to(DEV).train()
+    assert torch.isfinite(train.train_step(m0, train.build_optimizer(m0, conf0), conf0, x, y))
