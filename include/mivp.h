@@ -405,11 +405,17 @@ int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip
 /* logits f32 [B, vol, C] channels-last (C <= 8), target f32 [B, vol] class indices.
  * loss[0] = mean_bc dice_bc + mean focal (MONAI DiceFocalLoss(include_background, to_onehot_y, softmax,
  * gamma) as documented; class 0 dropped when include_background == 0); dlogits f32 [B, vol, C] = d loss / d logits.
- * workspace: mivp_dice_focal_ws(B, vol) floats.                                                    */
+ * workspace: mivp_dice_focal_ws(B, vol) floats.
+ * dlogits may be NULL (ABI 10): the value pass alone; the gradient pass then runs when autograd asks for it,
+ * mivp_dice_focal_grad on the SAME workspace (it holds the per-sample Dice sums), scaled by gscale[0] (device pointer to
+ * the incoming d total / d loss, NULL = 1) inside the pass instead of a second sweep over the 28 MB gradient.          */
 size_t mivp_dice_focal_ws(int32_t B, int64_t vol);
 int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
                     int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
                     mivp_stream_t stream);
+int mivp_dice_focal_grad(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
+                         int32_t include_background, float gamma, float* workspace, const float* gscale, float* dlogits,
+                         mivp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* downstream head on the LOW-resolution decoder output                      */

@@ -191,9 +191,10 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
 template <int C, bool VEC>
 __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict__ z, const float* __restrict__ y, long vol,
                                                          int B, int c0, float gamma, const float* __restrict__ stats,
-                                                         float* __restrict__ dz) {
+                                                         const float* __restrict__ gscale, float* __restrict__ dz) {
     const int K = 3 * LOSS_MAXC + 1;
     const long total = (long)B * vol;
+    const float up = gscale ? gscale[0] : 1.f;                 // the incoming d(total)/d(loss): folded in here, not a second pass
     const float ncls = (float)(C - c0);
     const float wd = 1.f / ((float)B * ncls), wf = 1.f / ((float)B * ncls * (float)vol);
     if (VEC) {
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
             voxel_grad<C>(zb + 3 * C, (int)y4.w, c0, gamma, wf, qa, qb, gb + 3 * C);
 #pragma unroll
             for (int j = 0; j < C; ++j)
-                *reinterpret_cast<float4*>(dz + i * C + 4 * j) = make_float4(gb[4 * j], gb[4 * j + 1], gb[4 * j + 2], gb[4 * j + 3]);
+                *reinterpret_cast<float4*>(dz + i * C + 4 * j) = make_float4(up * gb[4 * j], up * gb[4 * j + 1], up * gb[4 * j + 2], up * gb[4 * j + 3]);
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
             dice_consts<C>(stats + b * K, c0, wd, qa, qb);
             voxel_grad<C>(zz, (int)y[i], c0, gamma, wf, qa, qb, gz);
 #pragma unroll
-            for (int c = 0; c < C; ++c) dz[i * C + c] = gz[c];
+            for (int c = 0; c < C; ++c) dz[i * C + c] = up * gz[c];
         }
     }
 }
@@ -239,11 +240,9 @@ extern "C" size_t mivp_dice_focal_ws(int32_t B, int64_t vol) {
     return (size_t)B * (bpb + 1) * (3 * LOSS_MAXC + 1);
 }
 
-extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
-                               int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
-                               mivp_stream_t stream) {
-    MIVP_REQUIRE(logits && target && workspace && loss && dlogits);
-    MIVP_REQUIRE(B > 0 && vol > 0 && C >= 2 && C <= LOSS_MAXC);
+static int dice_focal_run(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C, int32_t include_background,
+                          float gamma, float* workspace, float* loss, const float* gscale, float* dlogits, bool do_loss,
+                          mivp_stream_t stream) {
     const int K = 3 * LOSS_MAXC + 1;
     long bpb = (vol + 256 * 4 - 1) / (256 * 4);
     if (bpb > 1024) bpb = 1024;
@@ -258,25 +257,44 @@ extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t
         case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;              \
     }
     const bool vec = vol % 4 == 0;                             // 16-byte loads of four voxels
+    if (do_loss) {
 #define L_STATS(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_stats<CC, true>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, \
                                                      logits, target, (long)vol, c0, gamma, (int)bpb, part);                    \
                          else hipLaunchKernelGGL((k_dice_focal_stats<CC, false>), dim3((unsigned)(B * bpb)), dim3(256), 0, st,    \
                                                  logits, target, (long)vol, c0, gamma, (int)bpb, part); } while (0)
-    LOSS_C_SWITCH(L_STATS)
+        LOSS_C_SWITCH(L_STATS)
 #undef L_STATS
-    int rc = mivp_check_launch("dice_focal_stats");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(1024), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
-    rc = mivp_check_launch("dice_focal_finalize");
-    if (rc) return rc;
+        int rc = mivp_check_launch("dice_focal_stats");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(1024), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
+        rc = mivp_check_launch("dice_focal_finalize");
+        if (rc) return rc;
+    }
+    if (!dlogits) return MIVP_OK;
     const long total = vec ? (long)B * vol / 4 : (long)B * vol;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define L_GRAD(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_grad<CC, true>), dim3(grid), dim3(256), 0, st, logits, target, \
-                                                    (long)vol, (int)B, c0, gamma, stats, dlogits);                            \
+                                                    (long)vol, (int)B, c0, gamma, stats, gscale, dlogits);                    \
                         else hipLaunchKernelGGL((k_dice_focal_grad<CC, false>), dim3(grid), dim3(256), 0, st, logits, target,   \
-                                                (long)vol, (int)B, c0, gamma, stats, dlogits); } while (0)
+                                                (long)vol, (int)B, c0, gamma, stats, gscale, dlogits); } while (0)
     LOSS_C_SWITCH(L_GRAD)
 #undef L_GRAD
 #undef LOSS_C_SWITCH
     return mivp_check_launch("dice_focal_grad");
+}
+
+extern "C" int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
+                               int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
+                               mivp_stream_t stream) {
+    MIVP_REQUIRE(logits && target && workspace && loss);
+    MIVP_REQUIRE(B > 0 && vol > 0 && C >= 2 && C <= LOSS_MAXC);
+    return dice_focal_run(logits, target, B, vol, C, include_background, gamma, workspace, loss, nullptr, dlogits, true, stream);
+}
+
+extern "C" int mivp_dice_focal_grad(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
+                                    int32_t include_background, float gamma, float* workspace, const float* gscale,
+                                    float* dlogits, mivp_stream_t stream) {
+    MIVP_REQUIRE(logits && target && workspace && dlogits);
+    MIVP_REQUIRE(B > 0 && vol > 0 && C >= 2 && C <= LOSS_MAXC);
+    return dice_focal_run(logits, target, B, vol, C, include_background, gamma, workspace, nullptr, gscale, dlogits, false, stream);
 }

@@ -90,7 +90,8 @@ def students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: 
     if conf.training_mode in ("supervised_learning_decoder", "supervised_learning_all") and getattr(conf, "use_real_label", True):
         total = total + dice_loss(out_sts[0]["seg_pred"], batch["mask_st_0"], conf.include_background)
     optimizer.zero_grad(set_to_none=True)
-    total.backward()
+    from .train import unit_grad
+    total.backward(unit_grad(total))
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

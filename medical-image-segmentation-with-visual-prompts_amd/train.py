@@ -76,7 +76,8 @@ def synthetic_batch(conf: Namespace, batch: int, size: int, device, rank: int = 
 
 
 class _DiceFocalFn(torch.autograd.Function):
-    """Loss value and d loss / d logits from two streaming HIP passes (csrc/loss.hip)."""
+    """Loss value from one streaming pass + a tiny reduction; d loss / d logits from a second streaming pass when backward
+    asks for it, already multiplied by the incoming gradient (csrc/loss.hip)."""
 
     @staticmethod
     def forward(ctx, logits_cl, target, include_background, gamma):
@@ -86,16 +87,23 @@ class _DiceFocalFn(torch.autograd.Function):
         vol = H * W * D
         ws = torch.empty(L.lib().mivp_dice_focal_ws(C.c_int32(B), C.c_int64(vol)), dtype=torch.float32, device=logits_cl.device)
         loss = torch.empty(1, dtype=torch.float32, device=logits_cl.device)
-        dz = torch.empty_like(logits_cl)
         L.call("mivp_dice_focal", L.ptr(logits_cl), L.ptr(target), C.c_int32(B), C.c_int64(vol), C.c_int32(Cc),
-               C.c_int32(1 if include_background else 0), C.c_float(gamma), L.ptr(ws), L.ptr(loss), L.ptr(dz), L.stream())
-        ctx.save_for_backward(dz)
+               C.c_int32(1 if include_background else 0), C.c_float(gamma), L.ptr(ws), L.ptr(loss), L.ptr(None), L.stream())
+        ctx.save_for_backward(logits_cl, target, ws)
+        ctx.meta = (B, vol, Cc, include_background, gamma)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        (dz,) = ctx.saved_tensors
-        return dz * g, None, None, None
+        import ctypes as C
+        from . import _lib as L
+        logits_cl, target, ws = ctx.saved_tensors
+        B, vol, Cc, include_background, gamma = ctx.meta
+        g = g.detach().to(torch.float32).contiguous()
+        dz = torch.empty_like(logits_cl)
+        L.call("mivp_dice_focal_grad", L.ptr(logits_cl), L.ptr(target), C.c_int32(B), C.c_int64(vol), C.c_int32(Cc),
+               C.c_int32(1 if include_background else 0), C.c_float(gamma), L.ptr(ws), L.ptr(g), L.ptr(dz), L.stream())
+        return dz, None, None, None
 
 
 def dice_focal_loss(logits: torch.Tensor, target: torch.Tensor, include_background: bool = True,
@@ -178,11 +186,22 @@ def step_loss(out: dict, conf: Namespace, y) -> torch.Tensor:
     raise ValueError(f"{mode}: use mivp_amd.students_teacher.students_teacher_step (students_teacher.py:150-207)")
 
 
+_unit_grads = {}
+
+
+def unit_grad(loss: torch.Tensor) -> torch.Tensor:
+    """The constant 1 that starts ``backward`` (autograd otherwise fills a new ``ones_like(loss)`` every step: a launch)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    if key not in _unit_grads:
+        _unit_grads[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return _unit_grads[key]
+
+
 def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
     out = model(x)
     loss = step_loss(out, conf, y)
     opt.zero_grad(set_to_none=True)
-    loss.backward()
+    loss.backward(unit_grad(loss))
     opt.step()
     return loss.detach()
 
@@ -248,7 +267,7 @@ def graphed_train_step(model, opt, conf: Namespace, x, y, warmup: int = 2) -> Gr
         out = model(x)
         loss = step_loss(out, conf, y)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(unit_grad(loss))
         opt.step()
         return loss.detach()
 
