@@ -22,7 +22,13 @@ int mivp_tok_wide_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void*
 //   only ~22k tokens (700 waves for 1024 SIMDs), so several waves share a token tile and each
 //   takes a slice of the output tiles (the LayerNorm is recomputed per slice, it is cheap).
 // ---------------------------------------------------------------------------------------------
-template <int KS>
+//   CH12 (C = 48, head_dim 12, one column split -- stage 0 of every configuration, the largest token count): the 8-byte
+//   pieces of the MFMA lane map (token r, channels 4g..) are rows 24 bytes apart, i.e. 64 separate accesses per store for
+//   the texture-address unit.  A (q|k|v, head) chunk of a 16-token tile is 384 CONTIGUOUS bytes of the
+//   head-major layout (a tile never straddles a window: Nqp % 16 == 0), so the pieces are first moved into address
+//   order across the lanes (ds_bpermute: lane l takes piece l = token l/3, part l%3; the crossbar, no LDS memory) and
+//   leave as one 48-lane contiguous store per chunk.
+template <int KS, bool CH12>
 __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16_t* __restrict__ x,
                                                       const int* __restrict__ tok_src,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
@@ -86,6 +92,65 @@ __global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16
         }
     }
 
+    if constexpr (CH12) {
+        const unsigned Nqp = (unsigned)d.Nqp;
+        long chunk[2];                                          // element offset of head 0's chunk of each token tile
+        bool tile_live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long t0 = (tile0 + u) * 16;
+            tile_live[u] = t0 < T;
+            const unsigned tt = tile_live[u] ? (unsigned)t0 : 0u;
+            const unsigned bpu = tt / Nqp;
+            chunk[u] = ((long)bpu * 4 * Nqp + (tt - bpu * Nqp)) * 12;
+        }
+        const int dl = lane < 48 ? lane : 47, rq = dl / 3, gq = dl - 3 * rq;
+        int src_addr[4];
+        bool from_b[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int ch = 12 * h + 4 * gq;                     // channel of this lane's piece inside the q|k|v third
+            src_addr[h] = 4 * (rq + 16 * ((ch & 15) >> 2));
+            from_b[h] = (ch >> 4) != ((12 * h) >> 4);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const float sc = sl == 0 ? d.q_scale : (sl == 1 ? MIVP_LOG2E : 1.0f);
+            u32x2 pk[3][2];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                f32x4 acc0 = fzero4(), acc1 = fzero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 a = wfrag(wqkv, KS, 3 * sl + t, s, lane);
+                    acc0 = mfma16(a, xb[0][s], acc0);
+                    acc1 = mfma16(a, xb[1][s], acc1);
+                }
+                pk[t][0] = __builtin_bit_cast(u32x2, pack4(acc0 * sc));
+                pk[t][1] = __builtin_bit_cast(u32x2, pack4(acc1 * sc));
+            }
+            bf16_t* base = sl == 0 ? q : (sl == 1 ? k : v);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int ta = (12 * h) >> 4, tb = (12 * h + 8) >> 4;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    u32x2 piece;
+                    piece[0] = (unsigned)__builtin_amdgcn_ds_bpermute(src_addr[h], (int)pk[ta][u][0]);
+                    piece[1] = (unsigned)__builtin_amdgcn_ds_bpermute(src_addr[h], (int)pk[ta][u][1]);
+                    if (tb != ta) {
+                        const unsigned b0 = (unsigned)__builtin_amdgcn_ds_bpermute(src_addr[h], (int)pk[tb][u][0]);
+                        const unsigned b1 = (unsigned)__builtin_amdgcn_ds_bpermute(src_addr[h], (int)pk[tb][u][1]);
+                        piece[0] = from_b[h] ? b0 : piece[0];
+                        piece[1] = from_b[h] ? b1 : piece[1];
+                    }
+                    if (tile_live[u] && lane < 48)
+                        *reinterpret_cast<u32x2*>(base + (chunk[u] + (long)h * Nqp * 12 + 4 * lane)) = piece;
+                }
+            }
+        }
+        return;
+    }
     const int n_out = 3 * C;
     const int n_tiles = (n_out + 15) / 16;
     const int per_split = (n_tiles + gridDim.y - 1) / gridDim.y;
@@ -875,11 +940,14 @@ extern "C" int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int
     if (nsplit < 1) nsplit = 1;
     const dim3 grid(gx, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_QKV(K) hipLaunchKernelGGL((k_swin_qkv_fwd<K>), grid, dim3(256), 0, st, *d, (const bf16_t*)x, tok_src, \
-                                          ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v)
+#define LAUNCH_QKV2(K, CH) hipLaunchKernelGGL((k_swin_qkv_fwd<K, CH>), grid, dim3(256), 0, st, *d, (const bf16_t*)x, tok_src, \
+                                              ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v)
+#define LAUNCH_QKV(K) LAUNCH_QKV2(K, false)
+    // contiguous chunk stores (kernel header): C = 48 with four heads of 12, all output columns in one workgroup
+    const bool ch12 = d->C == 48 && d->heads == 4 && nsplit == 1 && d->Nqp % 16 == 0;
     switch (KS) {
         case 1: LAUNCH_QKV(1); break;
-        case 2: LAUNCH_QKV(2); break;
+        case 2: if (ch12) LAUNCH_QKV2(2, true); else LAUNCH_QKV(2); break;
         case 3: LAUNCH_QKV(3); break;
         case 4: LAUNCH_QKV(4); break;
         case 6: LAUNCH_QKV(6); break;
