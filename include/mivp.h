@@ -396,6 +396,17 @@ typedef struct MivpUpcatDesc {
 } MivpUpcatDesc;
 /* x [B,ih,iw,id,Cx] bf16, skip [B,oh,ow,od,Cs] bf16 -> y [B,oh,ow,od,Cx+Cs] bf16 */
 int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void* y, mivp_stream_t stream);
+/* ABI 11: the concat tensor of SwinUpBlock (unet_blocks.py:72-75: up -> cat -> norm_concat -> act -> conv_concat) is
+ * never stored un-normalised when nothing upstream needs a gradient:
+ *   mivp_upcat_stats       per-channel sum / sum of squares of the bf16-rounded upsample + concat values ->
+ *                          part [nblk][2*(Cx+Cs)] f32 in mivp_bn_stats' layout (mivp_bn_finalize reduces the nblk rows);
+ *                          nblk <= B*oh*ow workgroups, Cx/8 <= 128 (256 without skip), Cs/8 <= 128, id*Cx/8 <= 2048
+ *   mivp_upcat_affine_fwd  y = act(scale[c] * v + shift[c]) of the bf16-rounded concat value v (lrelu: slope 0.01),
+ *                          bit-identical to mivp_upcat_fwd followed by mivp_affine_act                                  */
+int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const void* skip, int32_t nblk, float* part,
+                     mivp_stream_t stream);
+int mivp_upcat_affine_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, const float* scale,
+                          const float* shift, int32_t lrelu, void* y, mivp_stream_t stream);
 /* dy [B,oh,ow,od,Cx+Cs] bf16 -> dx [B,ih,iw,id,Cx] bf16 (transposed stencil), dskip (slice copy; may be NULL) */
 int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip, mivp_stream_t stream);
 

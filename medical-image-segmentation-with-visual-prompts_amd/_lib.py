@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 

@@ -181,26 +181,113 @@ MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in, int align = 0) {
     return l;
 }
 
-// One workgroup per output row (b, oh, ow): the h/w interpolation (indices, weights, the four source row
-// pointers) is uniform for the block, a thread walks (od, channel group) items of the row -- no 64-bit divisions,
-// no weight-dependent branches (clamped neighbours are always in bounds, their weight is simply 0).
+// One workgroup per output row (b, oh, ow).  The h/w interpolation (indices, weights, the four source rows) is uniform
+// for the block, so the four rows are combined ONCE into an f32 row image in LDS -- hw[id][Cx] = sum_ij w_ij x_ij -- with
+// coalesced loads, and an output item (od, channel group) is two LDS reads and one lerp.  Read per item straight from
+// global memory the stencil was 8 sixteen-byte loads per 16 output bytes (680 MB of L1 traffic for the 127 MB concat tensor
+// of the last decoder stage: the texture-address unit, not HBM, set the kernel's time); staged, every source piece is
+// loaded once per workgroup (4x fewer vector-memory instructions).  No weight-dependent branches: clamped neighbours are
+// always in bounds, their weight is simply 0.
+// AFF: y = act(scale[c] * v + shift[c]) applied to the bf16-rounded concat value v (the BatchNorm affine + LeakyReLU that
+// follows the concat in SwinUpBlock, unet_blocks.py:72-75) -- bit-identical to k_upcat_fwd followed by k_affine_act,
+// without the round trip of the concat tensor (statistics: k_upcat_stats).
+struct UpRow { int b, oh, ow; };
+MIVP_DEV UpRow up_row(const MivpUpcatDesc& d, int row) {        // row = (b*OH + oh)*OW + ow
+    UpRow u;
+    u.ow = row % d.odims[1];
+    const int boh = row / d.odims[1];
+    u.oh = boh % d.odims[0];
+    u.b = boh / d.odims[0];
+    return u;
+}
+// hw[id][Cx] (f32, LDS) <- the (h, w)-interpolated source row of output row u.  Two halves so that the loads of the NEXT
+// row can travel while the current one is consumed: load() issues every load of the thread unconditionally (NIT pieces x
+// 4 rows, clamped index), store() combines and writes them; `base` walks rows longer than 256 NIT pieces.
+template <int NIT>
+struct UpStage {
+    bf16x8 a[NIT], b[NIT], c[NIT], e[NIT];
+    float w00, w01, w10, w11;
+    MIVP_DEV void load(const MivpUpcatDesc& d, const bf16_t* __restrict__ x, UpRow u, int tid, int base = 0) {
+        const int n = d.idims[2] * (d.Cx / 8);
+        const Lerp lh = lerp_axis(u.oh, d.scale[0], d.idims[0], d.align_corners);
+        const Lerp lw = lerp_axis(u.ow, d.scale[1], d.idims[1], d.align_corners);
+        const long in_row = (long)d.idims[2] * d.Cx;
+        const bf16_t* r00 = x + (((long)u.b * d.idims[0] + lh.i0) * d.idims[1] + lw.i0) * in_row;
+        const bf16_t* r01 = x + (((long)u.b * d.idims[0] + lh.i0) * d.idims[1] + lw.i1) * in_row;
+        const bf16_t* r10 = x + (((long)u.b * d.idims[0] + lh.i1) * d.idims[1] + lw.i0) * in_row;
+        const bf16_t* r11 = x + (((long)u.b * d.idims[0] + lh.i1) * d.idims[1] + lw.i1) * in_row;
+        w00 = lh.w0 * lw.w0; w01 = lh.w0 * lw.w1; w10 = lh.w1 * lw.w0; w11 = lh.w1 * lw.w1;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {                          // the row is contiguous: piece `it` at element 8 it
+            const int it = min(base + tid + 256 * k, n - 1);
+            a[k] = ld8(r00 + 8 * it); b[k] = ld8(r01 + 8 * it); c[k] = ld8(r10 + 8 * it); e[k] = ld8(r11 + 8 * it);
+        }
+    }
+    MIVP_DEV void store(const MivpUpcatDesc& d, float* hw, int tid, int base = 0) const {
+        const int n = d.idims[2] * (d.Cx / 8);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = base + tid + 256 * k;
+            if (it < n) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = w00 * (float)a[k][i] + w01 * (float)b[k][i] + w10 * (float)c[k][i] + w11 * (float)e[k][i];
+                    hi[i] = w00 * (float)a[k][4 + i] + w01 * (float)b[k][4 + i] + w10 * (float)c[k][4 + i] + w11 * (float)e[k][4 + i];
+                }
+                *reinterpret_cast<f32x4*>(hw + 8 * it) = lo;
+                *reinterpret_cast<f32x4*>(hw + 8 * it + 4) = hi;
+            }
+        }
+    }
+};
+// the bf16-rounded upsampled values of (od, channel group cg) from the staged row
+MIVP_DEV bf16x8 upcat_item(const MivpUpcatDesc& d, const float* hw, int od, int cg) {
+    const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2], d.align_corners);
+    const float* p0 = hw + ld.i0 * d.Cx + cg * 8;
+    const float* p1 = hw + ld.i1 * d.Cx + cg * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0), a1 = *reinterpret_cast<const f32x4*>(p0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1), b1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (bf16_t)(ld.w0 * a0[i] + ld.w1 * b0[i]);
+        o[4 + i] = (bf16_t)(ld.w0 * a1[i] + ld.w1 * b1[i]);
+    }
+    return o;
+}
+
+template <bool AFF>
 __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t* __restrict__ x,
-                                                   const bf16_t* __restrict__ skip, bf16_t* __restrict__ y) {
+                                                   const bf16_t* __restrict__ skip, bf16_t* __restrict__ y,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   int lrelu) {
+    extern __shared__ __attribute__((aligned(16))) char smem_up[];
+    float* hw = reinterpret_cast<float*>(smem_up);            // [id][Cx] f32
+    float* ssc = hw + d.idims[2] * d.Cx;                      // AFF: [Ct] scale | [Ct] shift
     const int Ct = d.Cx + d.Cs, G = Ct / 8, Gx = d.Cx / 8;
-    const int OW = d.odims[1], OD = d.odims[2];
-    const int row = blockIdx.x;                               // (b*OH + oh)*OW + ow
-    const int ow = row % OW;
-    const int boh = row / OW;
-    const int oh = boh % d.odims[0];
-    const int b = boh / d.odims[0];
-    const Lerp lh = lerp_axis(oh, d.scale[0], d.idims[0], d.align_corners);
-    const Lerp lw = lerp_axis(ow, d.scale[1], d.idims[1], d.align_corners);
-    const long in_row = (long)d.idims[2] * d.Cx;
-    const bf16_t* r00 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i0) * in_row;
-    const bf16_t* r01 = x + (((long)b * d.idims[0] + lh.i0) * d.idims[1] + lw.i1) * in_row;
-    const bf16_t* r10 = x + (((long)b * d.idims[0] + lh.i1) * d.idims[1] + lw.i0) * in_row;
-    const bf16_t* r11 = x + (((long)b * d.idims[0] + lh.i1) * d.idims[1] + lw.i1) * in_row;
-    const float w00 = lh.w0 * lw.w0, w01 = lh.w0 * lw.w1, w10 = lh.w1 * lw.w0, w11 = lh.w1 * lw.w1;
+    const int OD = d.odims[2];
+    const int row = blockIdx.x;
+    if (AFF)
+        for (int c = threadIdx.x; c < Ct; c += 256) { ssc[c] = scale[c]; ssc[Ct + c] = shift[c]; }
+    for (int base = 0; base < d.idims[2] * Gx; base += 256 * 2) {
+        UpStage<2> st;
+        st.load(d, x, up_row(d, row), threadIdx.x, base);
+        st.store(d, hw, threadIdx.x, base);
+    }
+    __syncthreads();
+    auto affine = [&](bf16x8 v, int c0) -> bf16x8 {
+        bf16x8 o;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ssc + c0), s1 = *reinterpret_cast<const f32x4*>(ssc + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(ssc + Ct + c0), h1 = *reinterpret_cast<const f32x4*>(ssc + Ct + c0 + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float f = (float)v[i] * (i < 4 ? s0[i & 3] : s1[i & 3]) + (i < 4 ? h0[i & 3] : h1[i & 3]);
+            if (lrelu) f = f > 0.f ? f : 0.01f * f;
+            o[i] = (bf16_t)f;
+        }
+        return o;
+    };
     bf16_t* yrow = y + (long)row * OD * Ct;
     const bf16_t* srow = skip ? skip + (long)row * OD * d.Cs : nullptr;
     // items ordered interpolation first, skip copies last: waves are homogeneous (a mixed wave runs both paths)
@@ -208,22 +295,89 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
     for (int it = threadIdx.x; it < OD * G; it += 256) {
         if (it >= nI) {
             const int j = it - nI, od = j / Gs, cg = j - od * Gs;
-            st8(yrow + od * Ct + (Gx + cg) * 8, ld8(srow + od * d.Cs + cg * 8));
+            bf16x8 sv = ld8(srow + od * d.Cs + cg * 8);
+            if (AFF) sv = affine(sv, (Gx + cg) * 8);
+            st8(yrow + od * Ct + (Gx + cg) * 8, sv);
             continue;
         }
         const int od = it / Gx, cg = it - od * Gx;
-        const Lerp ld = lerp_axis(od, d.scale[2], d.idims[2], d.align_corners);
-        const int o0 = ld.i0 * d.Cx + cg * 8, o1 = ld.i1 * d.Cx + cg * 8;
-        const bf16x8 a0 = ld8(r00 + o0), a1 = ld8(r00 + o1), b0 = ld8(r01 + o0), b1 = ld8(r01 + o1);
-        const bf16x8 c0 = ld8(r10 + o0), c1 = ld8(r10 + o1), e0 = ld8(r11 + o0), e1 = ld8(r11 + o1);
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float v0 = w00 * (float)a0[i] + w01 * (float)b0[i] + w10 * (float)c0[i] + w11 * (float)e0[i];
-            const float v1 = w00 * (float)a1[i] + w01 * (float)b1[i] + w10 * (float)c1[i] + w11 * (float)e1[i];
-            o[i] = (bf16_t)(ld.w0 * v0 + ld.w1 * v1);
-        }
+        bf16x8 o = upcat_item(d, hw, od, cg);
+        if (AFF) o = affine(o, cg * 8);
         st8(yrow + od * Ct + cg * 8, o);
+    }
+}
+
+// Per-channel sum / sum of squares of the upsample + concat tensor WITHOUT forming it (the BatchNorm statistics of
+// SwinUpBlock's norm_concat): the same bf16-rounded values k_upcat_fwd would write.  Workgroups stride over output rows;
+// a thread keeps ONE channel group for the whole kernel (waves 0-1:
+// interpolated channels, waves 2-3: skip channels, so waves are homogeneous), walks the row's d positions and accumulates in
+// registers; the block's partials meet in LDS in a fixed order -> part [gridDim.x][2 * Ct] as mivp_bn_stats writes them
+// (mivp_bn_finalize reduces the blocks).
+template <int NIT>
+__global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upcat_stats(MivpUpcatDesc d, const bf16_t* __restrict__ x,
+                                                     const bf16_t* __restrict__ skip, int rows, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem_up[];
+    float* lsum = reinterpret_cast<float*>(smem_up);          // [256][16]
+    float* hwbuf = lsum + 256 * 16;                           // [id][Cx] f32
+    const int Ct = d.Cx + d.Cs, Gx = d.Cx / 8, Gs = d.Cs / 8;
+    const int OD = d.odims[2];
+    const int tid = threadIdx.x;
+    const int nI = Gs ? 128 : 256;                            // threads on the interpolated channels (waves 0-1), the rest copy
+    const int perx = nI / Gx, pers = Gs ? 128 / Gs : 0;
+    const bool interp = tid < perx * Gx, copy = tid >= nI && tid - nI < pers * Gs;
+    const int cg = interp ? tid % Gx : (copy ? (tid - nI) % Gs : 0);
+    const int od0 = interp ? tid / Gx : (copy ? (tid - nI) / Gs : 0);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    // Occupancy, not software pipelining, hides the memory latency here (a row's loads held in registers across the
+    // previous row's arithmetic cost 146 VGPRs = 3 workgroups per CU, and a launch then lasted as many load round trips as
+    // a workgroup has rows): per row every load of the thread -- source pieces and skip pieces -- is issued at once, one
+    // image buffer, two barriers.
+    constexpr int NSK = 6;                                    // skip pieces per thread and batch
+    float* hw = hwbuf;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        UpStage<NIT> st;
+        st.load(d, x, up_row(d, row), tid);
+        const bf16_t* srow = skip + (long)row * OD * d.Cs;
+        bf16x8 sv[NSK];
+        if (copy) {
+#pragma unroll
+            for (int u = 0; u < NSK; ++u) sv[u] = ld8(srow + min(od0 + u * pers, OD - 1) * d.Cs + cg * 8);
+        }
+        st.store(d, hw, tid);
+        __syncthreads();
+        if (interp) {
+#pragma unroll 2
+            for (int od = od0; od < OD; od += perx) {
+                const bf16x8 v = upcat_item(d, hw, od, cg);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
+            }
+        } else if (copy) {
+#pragma unroll
+            for (int u = 0; u < NSK; ++u) {
+                const bf16x8 v = keep_if(sv[u], od0 + u * pers < OD);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
+            }
+            for (int od = od0 + NSK * pers; od < OD; od += pers) {          // (rows longer than NSK batches)
+                const bf16x8 v = ld8(srow + od * d.Cs + cg * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { lsum[tid * 16 + i] = s1[i]; lsum[tid * 16 + 8 + i] = s2[i]; }
+    __syncthreads();
+    for (int o = tid; o < 2 * Ct; o += 256) {
+        const int which = o / Ct, c = o - which * Ct, i = c & 7;
+        float acc = 0.f;
+        if (c < d.Cx) { for (int t = c >> 3; t < perx * Gx; t += Gx) acc += lsum[t * 16 + which * 8 + i]; }
+        else { for (int t = nI + ((c - d.Cx) >> 3); t < nI + pers * Gs; t += Gs) acc += lsum[t * 16 + which * 8 + i]; }
+        part[(long)blockIdx.x * 2 * Ct + o] = acc;
     }
 }
 
@@ -236,9 +390,60 @@ extern "C" int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void*
     }
     const long rows = (long)d->B * d->odims[0] * d->odims[1];
     MIVP_REQUIRE(rows < (1L << 31));
-    hipLaunchKernelGGL(k_upcat_fwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)x,
-                       (const bf16_t*)skip, (bf16_t*)y);
+    const size_t lds = sizeof(float) * (size_t)d->idims[2] * d->Cx;          // the (h, w)-combined source row
+    MIVP_REQUIRE(lds <= 160 * 1024);
+    MIVP_LDS_OPT_IN(k_upcat_fwd<false>, lds);
+    hipLaunchKernelGGL(k_upcat_fwd<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
+                       (const bf16_t*)skip, (bf16_t*)y, nullptr, nullptr, 0);
     return mivp_check_launch("upcat_fwd");
+}
+
+static int upcat_checks(const MivpUpcatDesc* d, const void* skip) {
+    MIVP_REQUIRE(d->Cx % 8 == 0 && d->Cs % 8 == 0 && d->Cx > 0 && (d->Cs == 0 || skip));
+    for (int a = 0; a < 3; ++a) {
+        MIVP_REQUIRE(d->scale[a] == 1 || d->scale[a] == 2);
+        MIVP_REQUIRE(d->odims[a] > 0 && d->odims[a] <= d->scale[a] * d->idims[a]);
+    }
+    MIVP_REQUIRE((long)d->B * d->odims[0] * d->odims[1] < (1L << 31));
+    return MIVP_OK;
+}
+
+extern "C" int mivp_upcat_affine_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, const float* scale,
+                                     const float* shift, int32_t lrelu, void* y, mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && y && scale && shift);
+    int rc = upcat_checks(d, skip);
+    if (rc) return rc;
+    const long rows = (long)d->B * d->odims[0] * d->odims[1];
+    const size_t lds = sizeof(float) * ((size_t)d->idims[2] * d->Cx + 2 * (size_t)(d->Cx + d->Cs));
+    MIVP_REQUIRE(lds <= 160 * 1024);
+    MIVP_LDS_OPT_IN(k_upcat_fwd<true>, lds);
+    hipLaunchKernelGGL(k_upcat_fwd<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
+                       (const bf16_t*)skip, (bf16_t*)y, scale, shift, (int)lrelu);
+    return mivp_check_launch("upcat_affine_fwd");
+}
+
+extern "C" int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const void* skip, int32_t nblk, float* part,
+                                mivp_stream_t stream) {
+    MIVP_REQUIRE(d && x && part && nblk > 0);
+    int rc = upcat_checks(d, skip);
+    if (rc) return rc;
+    MIVP_REQUIRE(d->Cx / 8 <= (d->Cs ? 128 : 256) && d->Cs / 8 <= 128);
+    const long rows = (long)d->B * d->odims[0] * d->odims[1];
+    MIVP_REQUIRE(nblk <= rows);
+    const size_t lds = sizeof(float) * (256 * 16 + (size_t)d->idims[2] * d->Cx);
+    const int pieces = d->idims[2] * (d->Cx / 8);                            // of a source row: all of them live in registers
+    MIVP_REQUIRE(lds <= 160 * 1024 && pieces <= 256 * 8);
+#define L_UPSTATS(N)                                                                                                           \
+    do {                                                                                                                      \
+        MIVP_LDS_OPT_IN(k_upcat_stats<N>, lds);                                                                               \
+        hipLaunchKernelGGL(k_upcat_stats<N>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,  \
+                           (const bf16_t*)skip, (int)rows, part);                                                             \
+    } while (0)
+    if (pieces <= 512) L_UPSTATS(2);
+    else if (pieces <= 1024) L_UPSTATS(4);
+    else L_UPSTATS(8);
+#undef L_UPSTATS
+    return mivp_check_launch("upcat_stats");
 }
 
 // backward: dx[i] = sum over output positions o whose stencil touches i of weight(o, i) * dy[o] (first Cx

@@ -71,6 +71,29 @@ MIVP_DEV void to_f32(bf16x8 v, float (&out)[8]) {
     for (int e = 0; e < 8; ++e) out[e] = (float)v[e];
 }
 
+// Piece-major walk over the workgroup's ROWS x C/8 sixteen-byte row pieces (the narrow stages: with two or four lanes per row
+// a wave instruction is 32- or 64-byte runs 2C bytes apart and the texture-address unit stays ~60 % busy): piece
+// P = tid + 256 i, row P / (C/8) -- adjacent lanes take adjacent pieces, so the token-major tensors (o, t1, dt1, dO) move as
+// whole 1 KB wave accesses and gathered / scattered voxel rows as runs of at least one row.
+template <int CT>
+struct FlatRows {
+    using G = WideGeom<CT>;
+    static constexpr int PPR = G::C / 8, N = G::XPT;
+    static_assert(G::ROWS * PPR == 256 * N, "pieces split evenly over the threads");
+    int prow[N], col[N];
+    RowTok tk[N];
+    MIVP_DEV FlatRows(const MivpSwinDesc& d, long row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int P = tid + 256 * i;
+            prow[i] = P / PPR;
+            col[i] = 8 * (P - prow[i] * PPR);
+            tk[i] = row_token(d, row0 + prow[i]);
+        }
+    }
+};
+template <int CT> constexpr bool flat_rows() { return CT == 3; }
+
 // Head-major q | k | v pieces of this workgroup's granules.  Per 32-token granule and (tensor, head) the tensor
 // [B*P*heads][Nqp][hd] holds one contiguous chunk of 32 * hd elements (Nqp % 32 == 0: a granule never leaves its window).
 // Piece P (8 bytes) of a granule: chunk = P / (8 hd), q = P % (8 hd) the piece within the chunk (token q / hd4, columns
@@ -233,9 +256,36 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
     const long row0 = (long)blockIdx.x * ROWS;
     const int row = tid / TPR, sub = tid % TPR;                  // the row phases' lane map
     const RowTok ti = row_token(d, row0 + row);
-    const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
-    const int dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
-    {   // ---- rows in: o, shortcut ----
+    constexpr bool FLAT = flat_rows<CT>();
+    int src = -2, dst = -1;
+    int fdst[XPT], fb[XPT];                                      // FLAT: scatter target and batch index of this thread's pieces
+    if (!FLAT) {
+        src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
+        dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
+    }
+    if (FLAT) {   // ---- rows in: o, shortcut (piece-major) ----
+        const FlatRows<CT> fr(d, row0, tid);
+        int fsrc[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            fsrc[i] = sel(fr.tk[i].live, tok_src[fr.tk[i].pw * d.Nqp + fr.tk[i].slot], -2);
+            fdst[i] = sel(fr.tk[i].live, tok_dst[fr.tk[i].pw * d.Nqp + fr.tk[i].slot], -1);
+        }
+        bf16x8 orow[XPT], xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            orow[i] = ld8(o + fr.tk[i].tt * (long)C + fr.col[i]);
+            xr[i] = ld8(x + (fr.tk[i].b * d.vol_in + max(fsrc[i], 0)) * (long)C + fr.col[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            RI::put8(Aimg, fr.prow[i], fr.col[i], keep_if(orow[i], fr.tk[i].live));
+            RI::put8(Ximg, fr.prow[i], fr.col[i], keep_if(xr[i], fsrc[i] >= 0));
+            fb[i] = (int)fr.tk[i].b;
+        }
+        if (G::KP != C && sub == 0)
+            for (int c = C; c < G::KP; c += 8) RI::put8(Aimg, row, c, zero8());          // the k-step padding of the B operand
+    } else {   // ---- rows in: o, shortcut ----
         const long xoff = (ti.b * d.vol_in + max(src, 0)) * (long)C;
         bf16x8 orow[XPT], xr[XPT];
 #pragma unroll
@@ -329,7 +379,13 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
         }
     }
     __syncthreads();
-    if (dst >= 0) {                                              // ---- rows out: scatter ----
+    if (FLAT) {                                                  // ---- rows out: scatter (piece-major) ----
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int P = tid + 256 * i, prow = P / (C / 8), col = 8 * (P - prow * (C / 8));
+            if (fdst[i] >= 0) st8(y + ((long)fb[i] * d.vol_out + fdst[i]) * (long)C + col, RI::frag(Ximg, prow, col));
+        }
+    } else if (dst >= 0) {                                       // ---- rows out: scatter ----
         const long yoff = (ti.b * d.vol_out + dst) * (long)C;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) st8(y + yoff + 8 * (sub + TPR * i), RI::frag(Ximg, row, 8 * (sub + TPR * i)));

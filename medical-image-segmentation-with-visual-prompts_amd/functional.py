@@ -560,15 +560,47 @@ class _BnActConvFn(torch.autograd.Function):
                 dw if need_cw else None, db if need_cb else None, None, None, None, None, None)
 
 
-def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
-    key = key or "bn_conv"
-
+def _bn_conv_weights(owner, key, conv):
     def build():
         wd, cpad = ops.pack_conv_weight_dgrad(conv.weight)
         return ops.pack_conv_weight(conv.weight), (wd, cpad, ops.pack_conv_weight_dgrad16(conv.weight))
 
-    wp, wd = owner._wcache.get(key, [conv.weight], build)
+    return owner._wcache.get(key, [conv.weight], build)
+
+
+def bn_act_conv(owner, bn, conv, x, lrelu, out_f32=False, key=None):
+    wp, wd = _bn_conv_weights(owner, key or "bn_conv", conv)
     return _BnActConvFn.apply(x, bn.weight, bn.bias, conv.weight, conv.bias, bn, wp, wd, lrelu, out_f32)
+
+
+USE_FUSED_UPCAT_BN = True
+
+
+def upcat_bn_act_conv(owner, bn, conv, x, skip, strides, lrelu=True, key=None):
+    """SwinUpBlock's up -> cat -> norm_concat -> act -> conv_concat (unet_blocks.py:72-75).  When nothing on the way needs
+    a gradient (frozen decoder without prompts: BASELINE configs[1]; evaluation) the concat tensor is never stored
+    un-normalised: its BatchNorm statistics come from the sources (``mivp_upcat_stats``) and one pass writes
+    act(BN(cat(up(x), skip))) for the conv (``mivp_upcat_affine_fwd``) -- three passes over the largest tensor of the
+    stage fewer than upcat -> statistics -> affine_act.  Otherwise the differentiable pair below."""
+    tensors = (x, skip, bn.weight, bn.bias, conv.weight, conv.bias)
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    fits = skip is not None and x.shape[3] * (x.shape[-1] // 8) <= 2048 and x.shape[-1] <= 1024 and skip.shape[-1] <= 1024
+    if needs_grad or not USE_FUSED_UPCAT_BN or not fits:
+        return bn_act_conv(owner, bn, conv, upcat(x, skip, strides), lrelu, key=key)
+    require_device(x)
+    wp, _ = _bn_conv_weights(owner, key or "bn_conv", conv)
+    strides = tuple(int(s) for s in strides)
+    with torch.no_grad():
+        if bn.training:
+            part, nblk, n_vox = ops.upcat_stats(x, skip, strides)
+            scale, shift, _ = ops.bn_finalize(part, nblk, x.shape[-1] + skip.shape[-1], n_vox,
+                                              bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous(),
+                                              bn.eps, bn.running_mean, bn.running_var, bn_momentum(bn))
+            bump_counter(bn.num_batches_tracked)
+        else:
+            scale, shift, _ = ops.bn_eval_affine(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        z = ops.upcat_affine(x, skip, strides, scale, shift, lrelu)
+        return ops.conv3d(z, wp, conv.bias.detach().float().contiguous(), conv.weight.shape[0])
 
 
 class _UpHeadFn(torch.autograd.Function):

@@ -496,6 +496,32 @@ def upcat(x, skip, scale: Sequence[int], odims: Optional[Sequence[int]] = None, 
     return y
 
 
+def _upcat_args(x, skip, scale, align_corners=False):
+    B, ih, iw, id_, cx = x.shape
+    odims = skip.shape[1:4] if skip is not None else (ih * scale[0], iw * scale[1], id_ * scale[2])
+    cs = skip.shape[-1] if skip is not None else 0
+    return upcat_desc(B, (ih, iw, id_), odims, scale, cx, cs, align_corners), tuple(odims), cx + cs
+
+
+def upcat_stats(x, skip, scale: Sequence[int]):
+    """Partial per-channel sums of the (never materialised) upsample + concat tensor: (part [nblk, 2*Ct], nblk, n_vox)."""
+    d, odims, ct = _upcat_args(x, skip, scale)
+    rows = x.shape[0] * odims[0] * odims[1]
+    nblk = min(rows, 2048)
+    part = torch.empty((nblk, 2 * ct), dtype=torch.float32, device=x.device)
+    L.call("mivp_upcat_stats", C.byref(d), L.ptr(x), L.ptr(skip), C.c_int32(nblk), L.ptr(part), L.stream())
+    return part, nblk, rows * odims[2]
+
+
+def upcat_affine(x, skip, scale: Sequence[int], bn_scale, bn_shift, lrelu: bool):
+    """act(BatchNorm-affine(cat(upsample(x), skip))) in one pass (bit-equal to upcat + affine_act)."""
+    d, odims, ct = _upcat_args(x, skip, scale)
+    y = torch.empty((x.shape[0],) + odims + (ct,), dtype=BF16, device=x.device)
+    L.call("mivp_upcat_affine_fwd", C.byref(d), L.ptr(x), L.ptr(skip), L.ptr(bn_scale), L.ptr(bn_shift),
+           C.c_int32(1 if lrelu else 0), L.ptr(y), L.stream())
+    return y
+
+
 def upcat_backward(dy, idims, scale, cx, cs, need_skip=True, align_corners=False):
     B = dy.shape[0]
     odims = dy.shape[1:4]

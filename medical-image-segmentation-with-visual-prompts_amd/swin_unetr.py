@@ -293,8 +293,7 @@ class SwinUpBlock(nn.Module):
         self._wcache = Fn.WeightCache()
 
     def forward(self, x, c, p=(None, None)):
-        y = Fn.upcat(x, c, self.strides)
-        y = Fn.bn_act_conv(self, self.norm_concat, self.conv_concat.conv, y, lrelu=True)
+        y = Fn.upcat_bn_act_conv(self, self.norm_concat, self.conv_concat.conv, x, c, self.strides, lrelu=True)
         return self.swin_layer(y, p)
 
     def named_parameters_body(self):

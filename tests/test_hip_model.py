@@ -507,3 +507,42 @@ def test_batched_prompt_operands_equal_the_per_block_path():
     for k in g1:
         if float(g2[k].norm()) > 0:
             assert rel_l2(g1[k], g2[k]) < 1e-5, (k, rel_l2(g1[k], g2[k]))
+
+
+def test_frozen_decoder_without_the_concat_tensor_equals_the_materialised_path():
+    """SwinUpBlock with nothing to differentiate (downstream, no prompts: BASELINE configs[1]) takes
+    functional.upcat_bn_act_conv's fused branch -- statistics from the sources, one pass writing act(BN(cat)) -- and must
+    reproduce the materialised upcat -> BatchNorm -> act -> conv path: activations are bit-equal given equal statistics,
+    the statistics differ by f32 summation order only.  Running statistics and step counters must move identically."""
+    import mivp_amd
+    from mivp_amd import functional as Fn
+    from mivp_amd.swin_unetr import SwinUnetR
+    fx = load_fixture("unetr_downstream_e0d0")
+    conf = Namespace(**fx.meta["conf"])
+    sd = round_weights(fx["sd"])
+    x = fx["in"]["x"].to(DEV)
+    runs = []
+    for fused in (True, False):
+        model = SwinUnetR(conf)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train()
+        keep = Fn.USE_FUSED_UPCAT_BN
+        Fn.USE_FUSED_UPCAT_BN = fused
+        calls = []
+        orig = Fn.ops.upcat_stats
+        Fn.ops.upcat_stats = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            out = model(x)["downstream"]
+            Fn.flush_counters()
+        finally:
+            Fn.USE_FUSED_UPCAT_BN = keep
+            Fn.ops.upcat_stats = orig
+        torch.cuda.synchronize()
+        assert (len(calls) > 0) == fused                      # the branch under test really ran
+        bufs = {k: v.detach().float().cpu() for k, v in model.named_buffers() if "norm_concat" in k}
+        runs.append((out.detach().float().cpu(), bufs))
+    (o1, b1), (o2, b2) = runs
+    assert rel_l2(o1, o2) < 2e-4, rel_l2(o1, o2)
+    assert sorted(b1) == sorted(b2) and len(b1) > 0
+    for k in b1:
+        assert rel_l2(b1[k], b2[k]) < 1e-5, (k, rel_l2(b1[k], b2[k]))

@@ -239,6 +239,41 @@ def test_upcat_fwd_bwd(idims, sdims, scale, cx, cs):
         assert rel_l2(cf(dskip), skip.grad) < 1e-6
 
 
+@pytest.mark.parametrize("idims,sdims,scale,cx,cs", [
+    ((3, 3, 4), (6, 6, 4), (2, 2, 1), 16, 8),
+    ((3, 4, 2), (5, 7, 4), (2, 2, 2), 16, 8),          # crop
+    ((12, 12, 12), (24, 24, 24), (2, 2, 2), 96, 48),   # decoder stage shape (channels), several rows per workgroup
+    ((3, 3, 3), (6, 6, 6), (2, 2, 2), 384, 192),       # widest decoder stage
+    ((2, 3, 24), (4, 6, 24), (2, 2, 1), 384, 192),     # its 96^3 shape: d not halved, 1152 pieces per source row
+    ((2, 2, 12), (4, 4, 24), (2, 2, 2), 384, 192),     # 576 pieces
+])
+def test_upcat_statistics_and_affine_without_the_concat_tensor(idims, sdims, scale, cx, cs):
+    """mivp_upcat_stats / mivp_upcat_affine_fwd (SwinUpBlock's frozen-decoder path) against the materialised pipeline
+    upcat -> bn_stats -> affine_act: the activations bit for bit, the statistics to f32 summation order."""
+    from mivp_amd import ops
+    g = torch.Generator().manual_seed(cx + cs + idims[0])
+    x = cl(r16(torch.randn(2, cx, *idims, generator=g) + 0.3))
+    skip = cl(r16(torch.randn(2, cs, *sdims, generator=g) - 0.1))
+    ct = cx + cs
+    gamma = (1 + 0.2 * torch.randn(ct, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(ct, generator=g)).to(DEV)
+    cat = ops.upcat(x, skip, scale)
+    rm0, rv0 = torch.zeros(ct, device=DEV), torch.ones(ct, device=DEV)
+    sc0, sh0, mr0 = ops.bn_batch_stats(cat, gamma, beta, 1e-5, rm0, rv0, 0.1)
+    part, nblk, n_vox = ops.upcat_stats(x, skip, scale)
+    assert n_vox == cat.numel() // ct
+    rm1, rv1 = torch.zeros(ct, device=DEV), torch.ones(ct, device=DEV)
+    sc1, sh1, mr1 = ops.bn_finalize(part, nblk, ct, n_vox, gamma, beta, 1e-5, rm1, rv1, 0.1)
+    torch.cuda.synchronize()
+    assert rel_l2(sc1, sc0) < 1e-6 and rel_l2(sh1, sh0) < 1e-5 and rel_l2(mr1, mr0) < 1e-6
+    assert rel_l2(rm1, rm0) < 1e-5 and rel_l2(rv1, rv0) < 1e-6
+    for lrelu in (True, False):
+        want = ops.affine_act(cat, sc0, sh0, lrelu)
+        got = ops.upcat_affine(x, skip, scale, sc0, sh0, lrelu)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("cin,cout,dims,training", [(48, 2, (6, 8, 8), True), (48, 5, (4, 5, 7), False), (8, 2, (5, 4, 33), True)])
 def test_head_backward_from_one_mfma_pass(cin, cout, dims, training):
     """conv dW/db and BatchNorm dgamma/dbeta of the (BN -> conv) head all come from (G, S) of
