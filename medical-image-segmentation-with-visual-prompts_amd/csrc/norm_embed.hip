@@ -164,25 +164,32 @@ extern "C" int mivp_bn_stats(const void* x, int64_t n_vox, int32_t C, int32_t nb
 }
 
 // part [nblk][2C] -> batch mean / biased var -> scale, shift ; running stats (unbiased var) ; mean_rstd
-// one 64-lane wave per channel: lanes stride over the partial blocks in double precision, then a butterfly
-__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ part, int nblk, int C, double count,
-                                                    const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                    float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                    float* __restrict__ scale, float* __restrict__ shift,
-                                                    float* __restrict__ mean_rstd) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+// one 256-thread workgroup per channel: threads stride over the partial blocks in double precision (with 1024 partial rows
+// every load of a thread is in flight at once: one memory round trip instead of two to four for a single wave), a butterfly
+// per wave, then the four wave sums in wave order (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nblk, int C, double count,
+                                                     const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                     float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                     float* __restrict__ mean_rstd) {
+    __shared__ double wsum[4][2];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double s1 = 0.0, s2 = 0.0;
-    int i = lane;
-    for (; i + 64 * 7 < nblk; i += 64 * 8) {                     // 16 independent loads per round trip, same summation order
-        float v1[8], v2[8];
+    int i = tid;
+    for (; i + 256 * 3 < nblk; i += 256 * 4) {                   // 8 independent loads per round trip, same summation order
+        float v1[4], v2[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { v1[u] = part[(long)(i + 64 * u) * 2 * C + c]; v2[u] = part[(long)(i + 64 * u) * 2 * C + C + c]; }
+        for (int u = 0; u < 4; ++u) { v1[u] = part[(long)(i + 256 * u) * 2 * C + c]; v2[u] = part[(long)(i + 256 * u) * 2 * C + C + c]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+        for (int u = 0; u < 4; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
     }
-    for (; i < nblk; i += 64) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
+    for (; i < nblk; i += 256) { s1 += (double)part[(long)i * 2 * C + c]; s2 += (double)part[(long)i * 2 * C + C + c]; }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane != 0) return;
+    if (lane == 0) { wsum[wv][0] = s1; wsum[wv][1] = s2; }
+    __syncthreads();
+    if (tid != 0) return;
+    s1 = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);
+    s2 = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -202,7 +209,7 @@ extern "C" int mivp_bn_finalize(const float* part, int32_t nblk, int32_t C, doub
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                 float* shift, float* mean_rstd, mivp_stream_t stream) {
     MIVP_REQUIRE(part && scale && shift && nblk > 0 && C > 0 && count > 0);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, (hipStream_t)stream, part, (int)nblk, (int)C, count,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, (int)C, count,
                        w, b, eps, momentum, running_mean, running_var, scale, shift, mean_rstd);
     return mivp_check_launch("bn_finalize");
 }
