@@ -38,7 +38,7 @@ def test_capturable_adamw_is_bit_equal_to_the_plain_launch():
     assert oa.state_dict()["state"][0]["step"] == ob.state_dict()["state"][0]["step"] == 6
 
 
-@pytest.mark.parametrize("workload", ["tiny", "sup_all_small"])
+@pytest.mark.parametrize("workload", ["tiny", "sup_all_small", "cfg1_small"])
 def test_graphed_train_step_equals_the_eager_step(workload):
     """Six steps of the single-network trainer on a small volume: eager vs (two eager warm-up steps + four replays)."""
     import mivp_amd  # noqa: F401
@@ -46,6 +46,9 @@ def test_graphed_train_step_equals_the_eager_step(workload):
     from mivp_amd.swin_unetr import SwinUnetR
     if workload == "tiny":
         conf, size, batch = train.make_conf("tiny")
+    elif workload == "cfg1_small":                              # frozen decoder without prompts: the concat-free up-block path
+        conf, size, batch = train.make_conf("cfg1")
+        size, batch = 32, 2
     else:                                                       # every parameter trains (weight-gradient kernels of all blocks)
         conf, size, batch = train.make_conf("sup_all")
         size, batch = 32, 2
