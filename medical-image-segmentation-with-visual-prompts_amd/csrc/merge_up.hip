@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
 
 // Per-channel sum / sum of squares of the upsample + concat tensor WITHOUT forming it (the BatchNorm statistics of
 // SwinUpBlock's norm_concat): the same bf16-rounded values k_upcat_fwd would write.  Workgroups stride over output rows;
-// a thread keeps ONE channel group for the whole kernel (waves 0-1:
-// interpolated channels, waves 2-3: skip channels, so waves are homogeneous), walks the row's d positions and accumulates in
+// a thread keeps ONE channel group for the whole kernel (waves 0-2:
+// interpolated channels, wave 3: skip channels, so waves are homogeneous), walks the row's d positions and accumulates in
 // registers; the block's partials meet in LDS in a fixed order -> part [gridDim.x][2 * Ct] as mivp_bn_stats writes them
 // (mivp_bn_finalize reduces the blocks).
 template <int NIT>
@@ -322,8 +322,11 @@ __global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upca
     const int Ct = d.Cx + d.Cs, Gx = d.Cx / 8, Gs = d.Cs / 8;
     const int OD = d.odims[2];
     const int tid = threadIdx.x;
-    const int nI = Gs ? 128 : 256;                            // threads on the interpolated channels (waves 0-1), the rest copy
-    const int perx = nI / Gx, pers = Gs ? 128 / Gs : 0;
+    // The kernel is bound by instruction issue (~600 instructions per wave and row: profiles/README.md), so the roles are
+    // balanced by instruction count: an interpolated item costs ~75 instructions, a copied one ~25 -- three waves
+    // interpolate, one copies.
+    const int nI = Gs ? 192 : 256;
+    const int perx = nI / Gx, pers = Gs ? 64 / Gs : 0;
     const bool interp = tid < perx * Gx, copy = tid >= nI && tid - nI < pers * Gs;
     const int cg = interp ? tid % Gx : (copy ? (tid - nI) % Gs : 0);
     const int od0 = interp ? tid / Gx : (copy ? (tid - nI) / Gs : 0);
@@ -361,10 +364,14 @@ __global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upca
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
             }
-            for (int od = od0 + NSK * pers; od < OD; od += pers) {          // (rows longer than NSK batches)
-                const bf16x8 v = ld8(srow + od * d.Cs + cg * 8);
+            for (int odb = od0 + NSK * pers; odb < OD; odb += NSK * pers) {  // (rows longer than one batch: further batches)
+                bf16x8 tv[NSK];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s1[i] += f; s2[i] += f * f; }
+                for (int u = 0; u < NSK; ++u) tv[u] = keep_if(ld8(srow + min(odb + u * pers, OD - 1) * d.Cs + cg * 8), odb + u * pers < OD);
+#pragma unroll
+                for (int u = 0; u < NSK; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float f = (float)tv[u][i]; s1[i] += f; s2[i] += f * f; }
             }
         }
         __syncthreads();
@@ -427,7 +434,7 @@ extern "C" int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const voi
     MIVP_REQUIRE(d && x && part && nblk > 0);
     int rc = upcat_checks(d, skip);
     if (rc) return rc;
-    MIVP_REQUIRE(d->Cx / 8 <= (d->Cs ? 128 : 256) && d->Cs / 8 <= 128);
+    MIVP_REQUIRE(d->Cx / 8 <= (d->Cs ? 192 : 256) && d->Cs / 8 <= 64);
     const long rows = (long)d->B * d->odims[0] * d->odims[1];
     MIVP_REQUIRE(nblk <= rows);
     const size_t lds = sizeof(float) * (256 * 16 + (size_t)d->idims[2] * d->Cx);

@@ -29,7 +29,7 @@ int mivp_tok_wide_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void*
 //   order across the lanes (ds_bpermute: lane l takes piece l = token l/3, part l%3; the crossbar, no LDS memory) and
 //   leave as one 48-lane contiguous store per chunk.
 template <int KS, bool CH12>
-__global__ __launch_bounds__(256) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void k_swin_qkv_fwd(MivpSwinDesc d, const bf16_t* __restrict__ x,
                                                       const int* __restrict__ tok_src,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                       const bf16_t* __restrict__ wqkv,

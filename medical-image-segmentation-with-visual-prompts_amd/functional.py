@@ -584,7 +584,7 @@ def upcat_bn_act_conv(owner, bn, conv, x, skip, strides, lrelu=True, key=None):
     stage fewer than upcat -> statistics -> affine_act.  Otherwise the differentiable pair below."""
     tensors = (x, skip, bn.weight, bn.bias, conv.weight, conv.bias)
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
-    fits = skip is not None and x.shape[3] * (x.shape[-1] // 8) <= 2048 and x.shape[-1] <= 1024 and skip.shape[-1] <= 1024
+    fits = skip is not None and x.shape[3] * (x.shape[-1] // 8) <= 2048 and x.shape[-1] <= 1536 and skip.shape[-1] <= 512
     if needs_grad or not USE_FUSED_UPCAT_BN or not fits:
         return bn_act_conv(owner, bn, conv, upcat(x, skip, strides), lrelu, key=key)
     require_device(x)
