@@ -400,7 +400,7 @@ int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void* skip, void
  * never stored un-normalised when nothing upstream needs a gradient:
  *   mivp_upcat_stats       per-channel sum / sum of squares of the bf16-rounded upsample + concat values ->
  *                          part [nblk][2*(Cx+Cs)] f32 in mivp_bn_stats' layout (mivp_bn_finalize reduces the nblk rows);
- *                          nblk <= B*oh*ow workgroups, Cx/8 <= 192 (256 without skip), Cs/8 <= 64, id*Cx/8 <= 2048
+ *                          nblk = nx*B*oh with 1 <= nx <= ow (nx workgroups walk one (b, oh) line of output rows), Cx/8 <= 192 (256 without skip), Cs/8 <= 64, id*Cx/8 <= 2048
  *   mivp_upcat_affine_fwd  y = act(scale[c] * v + shift[c]) of the bf16-rounded concat value v (lrelu: slope 0.01),
  *                          bit-identical to mivp_upcat_fwd followed by mivp_affine_act                                  */
 int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const void* skip, int32_t nblk, float* part,

@@ -166,6 +166,17 @@ struct Lerp { int i0, i1; float w0, w1; };
 MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in, int align = 0) {
     Lerp l;
     if (scale == 1) { l.i0 = l.i1 = o; l.w0 = 1.f; l.w1 = 0.f; return l; }
+    if (!align) {
+        // half-pixel centres, scale 2: source (o + 0.5) / 2 - 0.5 clamped at 0 = 0 | 0.25, 0.75 | 1.25, 1.75 | ... in integer form
+        // (the same values bit for bit -- 0.25 and 0.75 are exact -- in 6 instructions instead of ~15: these kernels are bound
+        // by instruction issue)
+        l.i0 = max(o - 1, 0) >> 1;
+        if (l.i0 > n_in - 1) l.i0 = n_in - 1;
+        l.i1 = l.i0 + (l.i0 < n_in - 1 ? 1 : 0);
+        l.w1 = o == 0 ? 0.f : ((o & 1) ? 0.25f : 0.75f);
+        l.w0 = 1.f - l.w1;
+        return l;
+    }
     float src;
     if (align) {                                              // align_corners=True: o * (n_in - 1) / (n_out - 1), n_out = 2 n_in
         src = (float)o * ((float)(n_in - 1) / (float)(2 * n_in - 1));
@@ -211,16 +222,18 @@ struct UpStage {
         const int n = d.idims[2] * (d.Cx / 8);
         const Lerp lh = lerp_axis(u.oh, d.scale[0], d.idims[0], d.align_corners);
         const Lerp lw = lerp_axis(u.ow, d.scale[1], d.idims[1], d.align_corners);
+        // four uniform row bases (scalar registers) + one 32-bit lane offset per piece: no per-lane 64-bit address arithmetic
         const long in_row = (long)d.idims[2] * d.Cx;
-        const bf16_t* r00 = x + (((long)u.b * d.idims[0] + lh.i0) * d.idims[1] + lw.i0) * in_row;
-        const bf16_t* r01 = x + (((long)u.b * d.idims[0] + lh.i0) * d.idims[1] + lw.i1) * in_row;
-        const bf16_t* r10 = x + (((long)u.b * d.idims[0] + lh.i1) * d.idims[1] + lw.i0) * in_row;
-        const bf16_t* r11 = x + (((long)u.b * d.idims[0] + lh.i1) * d.idims[1] + lw.i1) * in_row;
+        const bf16_t* xb = x + (long)u.b * d.idims[0] * d.idims[1] * in_row;
+        const bf16_t* r00 = xb + (long)(lh.i0 * d.idims[1] + lw.i0) * in_row;
+        const bf16_t* r01 = xb + (long)(lh.i0 * d.idims[1] + lw.i1) * in_row;
+        const bf16_t* r10 = xb + (long)(lh.i1 * d.idims[1] + lw.i0) * in_row;
+        const bf16_t* r11 = xb + (long)(lh.i1 * d.idims[1] + lw.i1) * in_row;
         w00 = lh.w0 * lw.w0; w01 = lh.w0 * lw.w1; w10 = lh.w1 * lw.w0; w11 = lh.w1 * lw.w1;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {                          // the row is contiguous: piece `it` at element 8 it
-            const int it = min(base + tid + 256 * k, n - 1);
-            a[k] = ld8(r00 + 8 * it); b[k] = ld8(r01 + 8 * it); c[k] = ld8(r10 + 8 * it); e[k] = ld8(r11 + 8 * it);
+            const unsigned it8 = 8u * (unsigned)min(base + tid + 256 * k, n - 1);
+            a[k] = ld8(r00 + it8); b[k] = ld8(r01 + it8); c[k] = ld8(r10 + it8); e[k] = ld8(r11 + it8);
         }
     }
     MIVP_DEV void store(const MivpUpcatDesc& d, float* hw, int tid, int base = 0) const {
@@ -267,12 +280,13 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
     float* ssc = hw + d.idims[2] * d.Cx;                      // AFF: [Ct] scale | [Ct] shift
     const int Ct = d.Cx + d.Cs, G = Ct / 8, Gx = d.Cx / 8;
     const int OD = d.odims[2];
-    const int row = blockIdx.x;
+    const UpRow urow{(int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x};       // grid (OW, OH, B): no divisions
+    const int row = (urow.b * d.odims[0] + urow.oh) * d.odims[1] + urow.ow;
     if (AFF)
         for (int c = threadIdx.x; c < Ct; c += 256) { ssc[c] = scale[c]; ssc[Ct + c] = shift[c]; }
     for (int base = 0; base < d.idims[2] * Gx; base += 256 * 2) {
         UpStage<2> st;
-        st.load(d, x, up_row(d, row), threadIdx.x, base);
+        st.load(d, x, urow, threadIdx.x, base);
         st.store(d, hw, threadIdx.x, base);
     }
     __syncthreads();
@@ -339,10 +353,15 @@ __global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upca
     // image buffer, two barriers.
     constexpr int NSK = 6;                                    // skip pieces per thread and batch
     float* hw = hwbuf;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    // grid (nx, OH, B): a workgroup keeps (b, oh) and walks ow = blockIdx.x, blockIdx.x + nx, ... (no divisions, the h
+    // interpolation is loop-invariant); its partial row is ((b * OH + oh) * nx + blockIdx.x)
+    const int OWd = d.odims[1];
+    const long row_base = ((long)blockIdx.z * d.odims[0] + blockIdx.y) * OWd;
+    for (int ow = blockIdx.x; ow < OWd; ow += gridDim.x) {
+        const long row = row_base + ow;
         UpStage<NIT> st;
-        st.load(d, x, up_row(d, row), tid);
-        const bf16_t* srow = skip + (long)row * OD * d.Cs;
+        st.load(d, x, UpRow{(int)blockIdx.z, (int)blockIdx.y, ow}, tid);
+        const bf16_t* srow = skip + row * OD * d.Cs;
         bf16x8 sv[NSK];
         if (copy) {
 #pragma unroll
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upca
         float acc = 0.f;
         if (c < d.Cx) { for (int t = c >> 3; t < perx * Gx; t += Gx) acc += lsum[t * 16 + which * 8 + i]; }
         else { for (int t = nI + ((c - d.Cx) >> 3); t < nI + pers * Gs; t += Gs) acc += lsum[t * 16 + which * 8 + i]; }
-        part[(long)blockIdx.x * 2 * Ct + o] = acc;
+        part[(((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 * Ct + o] = acc;
     }
 }
 
@@ -400,7 +419,8 @@ extern "C" int mivp_upcat_fwd(const MivpUpcatDesc* d, const void* x, const void*
     const size_t lds = sizeof(float) * (size_t)d->idims[2] * d->Cx;          // the (h, w)-combined source row
     MIVP_REQUIRE(lds <= 160 * 1024);
     MIVP_LDS_OPT_IN(k_upcat_fwd<false>, lds);
-    hipLaunchKernelGGL(k_upcat_fwd<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
+    MIVP_REQUIRE(d->odims[0] < 65536 && d->B < 65536);
+    hipLaunchKernelGGL(k_upcat_fwd<false>, dim3(d->odims[1], d->odims[0], d->B), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
                        (const bf16_t*)skip, (bf16_t*)y, nullptr, nullptr, 0);
     return mivp_check_launch("upcat_fwd");
 }
@@ -424,7 +444,8 @@ extern "C" int mivp_upcat_affine_fwd(const MivpUpcatDesc* d, const void* x, cons
     const size_t lds = sizeof(float) * ((size_t)d->idims[2] * d->Cx + 2 * (size_t)(d->Cx + d->Cs));
     MIVP_REQUIRE(lds <= 160 * 1024);
     MIVP_LDS_OPT_IN(k_upcat_fwd<true>, lds);
-    hipLaunchKernelGGL(k_upcat_fwd<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
+    MIVP_REQUIRE(d->odims[0] < 65536 && d->B < 65536);
+    hipLaunchKernelGGL(k_upcat_fwd<true>, dim3(d->odims[1], d->odims[0], d->B), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,
                        (const bf16_t*)skip, (bf16_t*)y, scale, shift, (int)lrelu);
     return mivp_check_launch("upcat_affine_fwd");
 }
@@ -436,14 +457,17 @@ extern "C" int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const voi
     if (rc) return rc;
     MIVP_REQUIRE(d->Cx / 8 <= (d->Cs ? 192 : 256) && d->Cs / 8 <= 64);
     const long rows = (long)d->B * d->odims[0] * d->odims[1];
-    MIVP_REQUIRE(nblk <= rows);
+    // nblk = nx * OH * B partial rows (ops.upcat_stats picks nx): nx workgroups share an output (b, oh) line
+    MIVP_REQUIRE(nblk % (d->B * d->odims[0]) == 0 && nblk / (d->B * d->odims[0]) <= d->odims[1]);
+    MIVP_REQUIRE(d->odims[0] < 65536 && d->B < 65536);
+    const dim3 grid3((unsigned)(nblk / (d->B * d->odims[0])), (unsigned)d->odims[0], (unsigned)d->B);
     const size_t lds = sizeof(float) * (256 * 16 + (size_t)d->idims[2] * d->Cx);
     const int pieces = d->idims[2] * (d->Cx / 8);                            // of a source row: all of them live in registers
     MIVP_REQUIRE(lds <= 160 * 1024 && pieces <= 256 * 8);
 #define L_UPSTATS(N)                                                                                                           \
     do {                                                                                                                      \
         MIVP_LDS_OPT_IN(k_upcat_stats<N>, lds);                                                                               \
-        hipLaunchKernelGGL(k_upcat_stats<N>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,  \
+        hipLaunchKernelGGL(k_upcat_stats<N>, grid3, dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,                 \
                            (const bf16_t*)skip, (int)rows, part);                                                             \
     } while (0)
     if (pieces <= 512) L_UPSTATS(2);

@@ -507,7 +507,8 @@ def upcat_stats(x, skip, scale: Sequence[int]):
     """Partial per-channel sums of the (never materialised) upsample + concat tensor: (part [nblk, 2*Ct], nblk, n_vox)."""
     d, odims, ct = _upcat_args(x, skip, scale)
     rows = x.shape[0] * odims[0] * odims[1]
-    nblk = min(rows, 1024)            # one resident round (4 workgroups per CU); mivp_bn_finalize walks the partial rows
+    lines = x.shape[0] * odims[0]     # nx workgroups walk one (b, oh) line: ~1024 workgroups = one resident round (4 per CU)
+    nblk = lines * max(1, min(odims[1], 1024 // lines))
     part = torch.empty((nblk, 2 * ct), dtype=torch.float32, device=x.device)
     L.call("mivp_upcat_stats", C.byref(d), L.ptr(x), L.ptr(skip), C.c_int32(nblk), L.ptr(part), L.stream())
     return part, nblk, rows * odims[2]
