@@ -94,17 +94,21 @@ __global__ __launch_bounds__(256, 4) void k_swin_qkv_fwd(MivpSwinDesc d, const b
 
     if constexpr (CH12) {
         const unsigned Nqp = (unsigned)d.Nqp;
+        // T % 32 == 0 here (the launcher asks for Nqp % 32 == 0): a wave's two tiles are live or dead together, and a dead
+        // wave leaves (no barrier in this instantiation)
+        if (tile0 * 16 >= T) return;
         long chunk[2];                                          // element offset of head 0's chunk of each token tile
-        bool tile_live[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const long t0 = (tile0 + u) * 16;
-            tile_live[u] = t0 < T;
-            const unsigned tt = tile_live[u] ? (unsigned)t0 : 0u;
-            const unsigned bpu = tt / Nqp;
+            const unsigned tt = (unsigned)((tile0 + u) * 16);
+            // (the division is expanded on the vector ALU: pin its uniform result to a scalar register, or every chunk address
+            // below is formed per lane in 64-bit vector arithmetic)
+            const unsigned bpu = (unsigned)__builtin_amdgcn_readfirstlane((int)(tt / Nqp));
             chunk[u] = ((long)bpu * 4 * Nqp + (tt - bpu * Nqp)) * 12;
         }
-        const int dl = lane < 48 ? lane : 47, rq = dl / 3, gq = dl - 3 * rq;
+        // lanes 48-63 repeat the pieces of lanes 32-47 (same bytes to the same addresses): no exec-mask region around each of
+        // the 24 stores (three scalar instructions and a branch apiece in a kernel bound by instruction issue)
+        const int dl = lane < 48 ? lane : lane - 16, rq = dl / 3, gq = dl - 3 * rq;
         int src_addr[4];
         bool from_b[4];
 #pragma unroll
@@ -122,7 +126,9 @@ __global__ __launch_bounds__(256, 4) void k_swin_qkv_fwd(MivpSwinDesc d, const b
                 f32x4 acc0 = fzero4(), acc1 = fzero4();
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const bf16x8 a = wfrag(wqkv, KS, 3 * sl + t, s, lane);
+                    // scalar fragment base + one 32-bit lane offset (the 64-bit per-lane form was two VALU instructions per load)
+                    const char* fb = reinterpret_cast<const char*>(wqkv) + (size_t)(((3 * sl + t) * KS + s) * 1024);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(fb + (unsigned)(16 * lane));
                     acc0 = mfma16(a, xb[0][s], acc0);
                     acc1 = mfma16(a, xb[1][s], acc1);
                 }
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(256, 4) void k_swin_qkv_fwd(MivpSwinDesc d, const b
                         piece[0] = from_b[h] ? b0 : piece[0];
                         piece[1] = from_b[h] ? b1 : piece[1];
                     }
-                    if (tile_live[u] && lane < 48)
-                        *reinterpret_cast<u32x2*>(base + (chunk[u] + (long)h * Nqp * 12 + 4 * lane)) = piece;
+                    char* cb = reinterpret_cast<char*>(base + (chunk[u] + (long)h * Nqp * 12));     // uniform
+                    *reinterpret_cast<u32x2*>(cb + (unsigned)(8 * dl)) = piece;
                 }
             }
         }
@@ -944,7 +950,7 @@ extern "C" int mivp_swin_qkv_fwd(const MivpSwinDesc* d, const void* x, const int
                                               ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v)
 #define LAUNCH_QKV(K) LAUNCH_QKV2(K, false)
     // contiguous chunk stores (kernel header): C = 48 with four heads of 12, all output columns in one workgroup
-    const bool ch12 = d->C == 48 && d->heads == 4 && nsplit == 1 && d->Nqp % 16 == 0;
+    const bool ch12 = d->C == 48 && d->heads == 4 && nsplit == 1 && d->Nqp % 32 == 0;
     switch (KS) {
         case 1: LAUNCH_QKV(1); break;
         case 2: if (ch12) LAUNCH_QKV2(2, true); else LAUNCH_QKV(2); break;
