@@ -148,7 +148,8 @@ int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, 
                      const float* ts, void* qa, void* ka, mivp_stream_t stream);
 
 /* softmax((q k^T + bias) * mask) v per (window, head)  (window_attention.py:49-59)
- *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 (natural log)
+ *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 (natural log; may be NULL
+ *   when no backward pass will follow -- ABI 11)
  *   tok_rid [P][Nqp] int32: shift-mask region id of every window slot, 0 <= id < 254 (27 regions in 3D)        */
 int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
                       const void* kp, const void* vp, const void* qa, const void* ka,

@@ -741,7 +741,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
                 const int j0 = 16 * dd + 4 * g;
                 if (j0 < hd) st4(ob + ((uint32_t)qrow[a] * C + j0), pack4(oacc[a][dd] * inv));
             }
-            if (g == 0) lse[bph * Nqp + qrow[a]] = (mrun[a] + __builtin_amdgcn_logf(ls)) * MIVP_LN2;
+            // lse feeds the backward passes only: a forward-only call (frozen block without prompts, evaluation) passes NULL
+            if (lse && g == 0) lse[bph * Nqp + qrow[a]] = (mrun[a] + __builtin_amdgcn_logf(ls)) * MIVP_LN2;
         }
     }
 }
@@ -1057,7 +1058,7 @@ extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const voi
                                  float* lse, mivp_stream_t stream) {
     int rc = swin_common_checks(d);
     if (rc) return rc;
-    MIVP_REQUIRE(q && k && v && qa && ka && o && lse);
+    MIVP_REQUIRE(q && k && v && qa && ka && o);             // lse may be NULL (ABI 11): forward only, nothing saved
     MIVP_REQUIRE(d->Np == 0 || (kp && vp));
     MIVP_REQUIRE(!d->has_mask || tok_rid);
     int dks, nt;

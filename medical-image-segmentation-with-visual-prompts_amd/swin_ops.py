@@ -242,8 +242,9 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
                     w.aug_cache = {}
                 w.aug_cache[aug_key] = (qa, ka)
     o = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev)
-    lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev)
     fp8 = USE_FP8_ATTN_FWD and hd < 16 and hd + d.augp <= 32 and not dropout
+    # the log-sum-exp rows feed the backward passes only (the fp8 experiment's kernel always writes them)
+    lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev) if (save or fp8) else None
     L.call("mivp_win_attn_fwd_fp8" if fp8 else "mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp),
            L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
     t1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if save else None
