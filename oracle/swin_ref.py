@@ -209,7 +209,7 @@ def shift_mask(geo: BlockGeometry) -> Optional[Tensor]:
 def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
                      bias: Optional[Tensor], mask: Optional[Tensor], n_query: int,
                      attn_keep: Optional[Tensor] = None, proj_keep: Optional[Tensor] = None,
-                     emulate_bf16: bool = False) -> Tensor:
+                     emulate_bf16: bool = False, zero_ref: bool = False) -> Tensor:
     """Windowed MHSA on normalised tokens ``y [B, P, Nk, C]``; returns the
     projected output for the first ``n_query`` rows ``[B, P, n_query, C]``.
 
@@ -244,6 +244,14 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
         logits = logits * mask[None, :, None]
     if emulate_bf16:
         pe = r16(torch.exp(logits - logits.amax(dim=-1, keepdim=True).detach()))
+        if zero_ref:
+            # Forward-only HIP calls (nothing saved for backward) form P = exp2(logit * log2 e) against a ZERO reference point
+            # (csrc/swin_fwd.hip, ZREF) and round THAT to bf16; only rows whose sum leaves [2^-100, 2^100) are redone
+            # against the running maximum.  The rounding pattern of P depends on the reference, so the emulation follows the
+            # same rule (row-wise; the kernel redoes whole 16-query tiles: visible only in the sharp-softmax stress cases).
+            pe0 = r16(torch.exp(logits.clamp(max=80.0)))
+            den0 = pe0.sum(dim=-1, keepdim=True)
+            pe = torch.where((den0 < 2.0 ** 100) & (den0 > 2.0 ** -100), pe0, pe)
         denom = pe.sum(dim=-1, keepdim=True)
         if attn_keep is not None:
             pe = pe * attn_keep
@@ -265,7 +273,7 @@ def window_attention(y: Tensor, sd: Dict[str, Tensor], prefix: str, heads: int,
 def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefix: str,
                window: Sequence[int], shift_cfg: Sequence[int], heads: int,
                embed_dim: int = 64, attn_keep: Optional[Tensor] = None,
-               proj_keep: Optional[Tensor] = None, emulate_bf16: bool = False) -> Tensor:
+               proj_keep: Optional[Tensor] = None, emulate_bf16: bool = False, zero_ref: bool = False) -> Tensor:
     """One SwinTransformerBlock, ``x [B,C,H,W,D]`` -> same shape (dropout only through the explicit
     multiplier masks of ``window_attention``).
 
@@ -296,7 +304,7 @@ def swin_block(x: Tensor, prompt: Optional[Tensor], sd: Dict[str, Tensor], prefi
     mask = shift_mask(geo)
     if mask is not None and n_prompt:
         mask = torch.cat([mask, mask.new_ones(geo.P, geo.N, n_prompt)], dim=2)   # :189-196
-    t1 = rr(window_attention(y, sd, prefix, heads, bias, mask, geo.N, attn_keep, proj_keep, emulate_bf16) + tok)
+    t1 = rr(window_attention(y, sd, prefix, heads, bias, mask, geo.N, attn_keep, proj_keep, emulate_bf16, zero_ref) + tok)
     t2 = rr(t1 + F.linear(rr(F.layer_norm(t1, (C,), sd[f"{prefix}mlp_norm.weight"], sd[f"{prefix}mlp_norm.bias"], 1e-6)),
                           sd[f"{prefix}mlp.weight"], sd[f"{prefix}mlp.bias"]))
     out = x.new_zeros(B, geo.padded[0] * geo.padded[1] * geo.padded[2], C)

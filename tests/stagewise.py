@@ -85,8 +85,8 @@ def hip_stages(conf, sd, x, device="cuda", gout=None):
 def stagewise_errors(conf, sd, x, emul=True, report=None):
     """{stage: (end-to-end rel-L2, restarted rel-L2)} of the HIP forward against the (rounding-aware) oracle."""
     from oracle import swin_ref as S
-    rec = hip_stages(conf, sd, x)
-    rr = S.r16 if emul else (lambda t: t)
+    rec = hip_stages(conf, sd, x)                             # gradients disabled: every block is a forward-only call, whose
+    rr = S.r16 if emul else (lambda t: t)                     # attention keeps the softmax reference at zero (oracle: zero_ref)
     win, E = conf.attn_window_size, conf.pos_bias_embed_dim
     shift = tuple(w // 2 for w in win)
     res = {}
@@ -107,11 +107,11 @@ def stagewise_errors(conf, sd, x, emul=True, report=None):
             pr = (sd[f"prompt_tokens.enc.{2*j}"], sd[f"prompt_tokens.enc.{2*j+1}"]) if conf.use_encoder_prompting else (None, None)
             pre = f"encoder_blocks.{j}."
             prev_name = "embed" if j == 0 else f"enc{j-1}.merge"
-            a = S.swin_block(e, pr[0], sd, pre + "swin_blocks.0.", win, (0, 0, 0), heads, E, emulate_bf16=emul)
-            a_r = S.swin_block(rec[prev_name], pr[0], sd, pre + "swin_blocks.0.", win, (0, 0, 0), heads, E, emulate_bf16=emul)
+            a = S.swin_block(e, pr[0], sd, pre + "swin_blocks.0.", win, (0, 0, 0), heads, E, emulate_bf16=emul, zero_ref=emul)
+            a_r = S.swin_block(rec[prev_name], pr[0], sd, pre + "swin_blocks.0.", win, (0, 0, 0), heads, E, emulate_bf16=emul, zero_ref=emul)
             note(f"enc{j}.b0", a, a_r)
-            b = S.swin_block(a, pr[1], sd, pre + "swin_blocks.1.", win, shift, heads, E, emulate_bf16=emul)
-            b_r = S.swin_block(rec[f"enc{j}.b0"], pr[1], sd, pre + "swin_blocks.1.", win, shift, heads, E, emulate_bf16=emul)
+            b = S.swin_block(a, pr[1], sd, pre + "swin_blocks.1.", win, shift, heads, E, emulate_bf16=emul, zero_ref=emul)
+            b_r = S.swin_block(rec[f"enc{j}.b0"], pr[1], sd, pre + "swin_blocks.1.", win, shift, heads, E, emulate_bf16=emul, zero_ref=emul)
             note(f"enc{j}.b1", b, b_r)
             e = S.patch_merge(b, sd, pre + "merge.", j < 1, emul)
             e_r = S.patch_merge(rec[f"enc{j}.b1"], sd, pre + "merge.", j < 1, emul)
@@ -142,11 +142,11 @@ def stagewise_errors(conf, sd, x, emul=True, report=None):
             note(f"dec{j}.upcat", c, c_r)
             y = bnconv(c); y_r = bnconv(rec[f"dec{j}.upcat"])
             note(f"dec{j}.conv", y, y_r)
-            a = S.swin_block(y, pr[0], sd, pre + "swin_layer.swin_blocks.0.", win, (0, 0, 0), conf.num_heads_decoder, E, emulate_bf16=emul)
-            a_r = S.swin_block(rec[f"dec{j}.conv"], pr[0], sd, pre + "swin_layer.swin_blocks.0.", win, (0, 0, 0), conf.num_heads_decoder, E, emulate_bf16=emul)
+            a = S.swin_block(y, pr[0], sd, pre + "swin_layer.swin_blocks.0.", win, (0, 0, 0), conf.num_heads_decoder, E, emulate_bf16=emul, zero_ref=emul)
+            a_r = S.swin_block(rec[f"dec{j}.conv"], pr[0], sd, pre + "swin_layer.swin_blocks.0.", win, (0, 0, 0), conf.num_heads_decoder, E, emulate_bf16=emul, zero_ref=emul)
             note(f"dec{j}.b0", a, a_r)
-            d = S.swin_block(a, pr[1], sd, pre + "swin_layer.swin_blocks.1.", win, shift, conf.num_heads_decoder, E, emulate_bf16=emul)
-            d_r = S.swin_block(rec[f"dec{j}.b0"], pr[1], sd, pre + "swin_layer.swin_blocks.1.", win, shift, conf.num_heads_decoder, E, emulate_bf16=emul)
+            d = S.swin_block(a, pr[1], sd, pre + "swin_layer.swin_blocks.1.", win, shift, conf.num_heads_decoder, E, emulate_bf16=emul, zero_ref=emul)
+            d_r = S.swin_block(rec[f"dec{j}.b0"], pr[1], sd, pre + "swin_layer.swin_blocks.1.", win, shift, conf.num_heads_decoder, E, emulate_bf16=emul, zero_ref=emul)
             note(f"dec{j}.b1", d, d_r)
             prev = f"dec{j}.b1"
 
