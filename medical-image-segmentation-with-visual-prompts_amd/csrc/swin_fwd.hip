@@ -620,22 +620,25 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int t = 2 * u + hh;
-                    f32x4 acc = negm[a];
+                    // ZREF optimistic steps: the reference point is the constant zero (an inline-constant accumulator seed)
+                    constexpr bool ZSEED = ZREF && OPT;
+                    const float masked_logit = ZSEED ? 0.f : negm[a][0];
+                    f32x4 acc = ZSEED ? fzero4() : negm[a];
 #pragma unroll
                     for (int s = 0; s < DKS; ++s) acc = mfma16(kfr[hh][s], qf[a][s], acc);
                     if (MASK) {
                         const uint32_t kr = kcl[hh];
                         if (!TAIL || t < nt_full) {
-                            acc[0] = ((kr & 0xFFu) == rq[a]) ? acc[0] : negm[a][0];
-                            acc[1] = (((kr >> 8) & 0xFFu) == rq[a]) ? acc[1] : negm[a][0];
-                            acc[2] = (((kr >> 16) & 0xFFu) == rq[a]) ? acc[2] : negm[a][0];
-                            acc[3] = ((kr >> 24) == rq[a]) ? acc[3] : negm[a][0];
+                            acc[0] = ((kr & 0xFFu) == rq[a]) ? acc[0] : masked_logit;
+                            acc[1] = (((kr >> 8) & 0xFFu) == rq[a]) ? acc[1] : masked_logit;
+                            acc[2] = (((kr >> 16) & 0xFFu) == rq[a]) ? acc[2] : masked_logit;
+                            acc[3] = ((kr >> 24) == rq[a]) ? acc[3] : masked_logit;
                         } else {                             // prompt / padding keys (254) are never masked
                             const uint32_t k0 = kr & 0xFFu, k1 = (kr >> 8) & 0xFFu, k2 = (kr >> 16) & 0xFFu, k3 = kr >> 24;
-                            acc[0] = (k0 == rq[a] || k0 == 254u) ? acc[0] : negm[a][0];
-                            acc[1] = (k1 == rq[a] || k1 == 254u) ? acc[1] : negm[a][0];
-                            acc[2] = (k2 == rq[a] || k2 == 254u) ? acc[2] : negm[a][0];
-                            acc[3] = (k3 == rq[a] || k3 == 254u) ? acc[3] : negm[a][0];
+                            acc[0] = (k0 == rq[a] || k0 == 254u) ? acc[0] : masked_logit;
+                            acc[1] = (k1 == rq[a] || k1 == 254u) ? acc[1] : masked_logit;
+                            acc[2] = (k2 == rq[a] || k2 == 254u) ? acc[2] : masked_logit;
+                            acc[3] = (k3 == rq[a] || k3 == 254u) ? acc[3] : masked_logit;
                         }
                     }
                     sv[a][hh] = acc;
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, con
                 if (j0 < hd) st4(ob + ((uint32_t)qrow[a] * C + j0), pack4(oacc[a][dd] * inv));
             }
             // lse feeds the backward passes only: a forward-only call (frozen block without prompts, evaluation) passes NULL
-            if (lse && g == 0) lse[bph * Nqp + qrow[a]] = (mrun[a] + __builtin_amdgcn_logf(ls)) * MIVP_LN2;
+            if (!ZREF && lse && g == 0) lse[bph * Nqp + qrow[a]] = (mrun[a] + __builtin_amdgcn_logf(ls)) * MIVP_LN2;
         }
     }
 }
