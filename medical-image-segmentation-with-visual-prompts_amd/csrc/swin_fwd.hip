@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   keep the first-step maximum: their rounding pattern is the one the backward parity bars were measured with
 //   (oracle/swin_ref.py models both: ``zero_ref``).
 template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED, bool ZREF = false>
-__global__ __launch_bounds__(64 * NW, 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 : 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
