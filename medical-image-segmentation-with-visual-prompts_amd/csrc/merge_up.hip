@@ -202,15 +202,7 @@ MIVP_DEV Lerp lerp_axis(int o, int scale, int n_in, int align = 0) {
 // AFF: y = act(scale[c] * v + shift[c]) applied to the bf16-rounded concat value v (the BatchNorm affine + LeakyReLU that
 // follows the concat in SwinUpBlock, unet_blocks.py:72-75) -- bit-identical to k_upcat_fwd followed by k_affine_act,
 // without the round trip of the concat tensor (statistics: k_upcat_stats).
-struct UpRow { int b, oh, ow; };
-MIVP_DEV UpRow up_row(const MivpUpcatDesc& d, int row) {        // row = (b*OH + oh)*OW + ow
-    UpRow u;
-    u.ow = row % d.odims[1];
-    const int boh = row / d.odims[1];
-    u.oh = boh % d.odims[0];
-    u.b = boh / d.odims[0];
-    return u;
-}
+struct UpRow { int b, oh, ow; };                              // an output row; the kernels take it from their 3-D grids
 // hw[id][Cx] (f32, LDS) <- the (h, w)-interpolated source row of output row u.  Two halves so that the loads of the NEXT
 // row can travel while the current one is consumed: load() issues every load of the thread unconditionally (NIT pieces x
 // 4 rows, clamped index), store() combines and writes them; `base` walks rows longer than 256 NIT pieces.
@@ -329,7 +321,7 @@ __global__ __launch_bounds__(256) void k_upcat_fwd(MivpUpcatDesc d, const bf16_t
 // (mivp_bn_finalize reduces the blocks).
 template <int NIT>
 __global__ __launch_bounds__(256, NIT <= 2 ? 4 : (NIT <= 4 ? 3 : 2)) void k_upcat_stats(MivpUpcatDesc d, const bf16_t* __restrict__ x,
-                                                     const bf16_t* __restrict__ skip, int rows, float* __restrict__ part) {
+                                                     const bf16_t* __restrict__ skip, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem_up[];
     float* lsum = reinterpret_cast<float*>(smem_up);          // [256][16]
     float* hwbuf = lsum + 256 * 16;                           // [id][Cx] f32
@@ -440,7 +432,6 @@ extern "C" int mivp_upcat_affine_fwd(const MivpUpcatDesc* d, const void* x, cons
     MIVP_REQUIRE(d && x && y && scale && shift);
     int rc = upcat_checks(d, skip);
     if (rc) return rc;
-    const long rows = (long)d->B * d->odims[0] * d->odims[1];
     const size_t lds = sizeof(float) * ((size_t)d->idims[2] * d->Cx + 2 * (size_t)(d->Cx + d->Cs));
     MIVP_REQUIRE(lds <= 160 * 1024);
     MIVP_LDS_OPT_IN(k_upcat_fwd<true>, lds);
@@ -456,7 +447,6 @@ extern "C" int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const voi
     int rc = upcat_checks(d, skip);
     if (rc) return rc;
     MIVP_REQUIRE(d->Cx / 8 <= (d->Cs ? 192 : 256) && d->Cs / 8 <= 64);
-    const long rows = (long)d->B * d->odims[0] * d->odims[1];
     // nblk = nx * OH * B partial rows (ops.upcat_stats picks nx): nx workgroups share an output (b, oh) line
     MIVP_REQUIRE(nblk % (d->B * d->odims[0]) == 0 && nblk / (d->B * d->odims[0]) <= d->odims[1]);
     MIVP_REQUIRE(d->odims[0] < 65536 && d->B < 65536);
@@ -468,7 +458,7 @@ extern "C" int mivp_upcat_stats(const MivpUpcatDesc* d, const void* x, const voi
     do {                                                                                                                      \
         MIVP_LDS_OPT_IN(k_upcat_stats<N>, lds);                                                                               \
         hipLaunchKernelGGL(k_upcat_stats<N>, grid3, dim3(256), lds, (hipStream_t)stream, *d, (const bf16_t*)x,                 \
-                           (const bf16_t*)skip, (int)rows, part);                                                             \
+                           (const bf16_t*)skip, part);                                                                        \
     } while (0)
     if (pieces <= 512) L_UPSTATS(2);
     else if (pieces <= 1024) L_UPSTATS(4);
