@@ -2,6 +2,7 @@
 // proj+MLP+scatter.  Reference semantics: swin_transformer/swin_block.py:145-255,
 // multi_head_attention/window_attention.py:35-61, relative_positional_encoding.py:99-142.
 #include "common.hpp"
+#include <cstdlib>
 
 // swin_tok_wide.hip: the column-split token kernels of the wide stages
 int mivp_tok_wide_supported(const MivpSwinDesc* d);
@@ -398,13 +399,33 @@ __global__ __launch_bounds__(256) void k_relbias_aug(MivpSwinDesc d, const float
 //   stage-0 launch).  A row sum outside [2^-100, 2^100) sends the tile to the tested walk.  Calls that save for backward
 //   keep the first-step maximum: their rounding pattern is the one the backward parity bars were measured with
 //   (oracle/swin_ref.py models both: ``zero_ref``).
-template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED, bool ZREF = false>
-__global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 : 2) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+// LDS-DMA staging helpers of the DMA form (below): constant source words (zero | bf16 (1, 0)), one 4-byte global -> LDS
+// transfer per lane (LDS address = wave-uniform base + 4 * lane), and the transposing LDS read (wgrad.hip)
+__device__ __attribute__((aligned(16))) unsigned int g_attn_consts[4] = {0u, 0x00003F80u, 0u, 0u};
+MIVP_DEV void glds4(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+typedef __attribute__((address_space(3))) bf16x4 attn_lds_bf16x4;
+MIVP_DEV bf16x4 attn_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((attn_lds_bf16x4*)p);
+}
+
+// waves per SIMD asked of the register allocator: the one-k-step kernels hold four workgroups per CU (34 KB of LDS each at 7^3
+// windows) when they fit 64 VGPRs
+template <int DKS, bool DROP, bool MASKED, bool ZREF, bool DMA>
+constexpr int attn_fwd_occupancy() {
+    if (DKS != 1 || DROP) return 2;
+    if (DMA) return MASKED ? 6 : 8;          // (the masked steps need ~70 VGPRs: at 64 they spill around every tile)
+    return (MASKED && ZREF) ? 8 : 2;
+}
+template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED, bool ZREF = false, bool DMA = false>
+__global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZREF, DMA>())) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
                                                          const int* __restrict__ tok_rid, bf16_t* __restrict__ o,
-                                                         float* __restrict__ lse) {
+                                                         float* __restrict__ lse, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DK = 32 * DKS;
     using KR = OperandRows<DK>;
@@ -413,18 +434,24 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
     // dropout, row head_dim of V^T is set to one, so O's row head_dim accumulates sum_k P -- of the same bf16-rounded P
     // the numerator uses -- and the eight adds per 32 keys leave the (binding) VALU stream.  (ONES is picked at launch.)
     const int Nkp = d.Nkp, Nqp = d.Nqp;
-    const int VROW = (Nkp + 8) * 2;                          // bytes
+    // DMA form (DKS == DVT == 1): V stays ROW-major [Nkp][16] (32-byte rows) and the PV product's A operand comes out of
+    // transposing reads; the classic form keeps a V^T image [16 DVT][Nkp + 8]
+    static_assert(!DMA || (DKS == 1 && DVT == 1), "the DMA-staged images are laid out for one k-step / one value tile");
+    const int VROW = DMA ? 32 : (Nkp + 8) * 2;               // bytes
     char* Kimg = smem;
     char* Vt = Kimg + (size_t)Nkp * KROW;
     // key classes as bytes (255 padding, 254 prompt, else region id): with 4-byte classes the image is 128 B over a
     // quarter of the CU's 160 KB at 7^3 windows, i.e. three workgroups per CU instead of four
-    uint8_t* ridk = reinterpret_cast<uint8_t*>(Vt + (size_t)(16 * DVT) * VROW);
+    uint8_t* ridk = reinterpret_cast<uint8_t*>(Vt + (DMA ? (size_t)Nkp * 32 : (size_t)(16 * DVT) * VROW));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the query-tile loop and its addresses stay in SGPRs
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C, heads = d.heads, hd = C / heads;
-    const long bph = blockIdx.x;                             // (b*P + pw)*heads + head
+    // (window, head) item of this workgroup: (b*P + pw)*heads + head.  Workgroups go round-robin over the 8 XCDs; with the
+    // remap consecutive items (the heads of a window, neighbouring windows) run on ONE XCD, i.e. meet in one L2
+    long bph = blockIdx.x;
+    if (xcd_remap) bph = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int head = (int)(bph % heads);
     const long bp = bph / heads;
     const int pw = (int)(bp % d.P);
@@ -440,6 +467,55 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
     const bf16_t* vpb = d.Np > 0 ? vp + (long)head * d.Npp * hd : vb;
     const bf16_t* kab = ka + (long)head * Nkp * A;
     const int n_prompt_rows = d.Np > 0 ? d.Npp : 0;
+    if constexpr (DMA) {
+        // ---- LDS-DMA staging (global_load_lds_dword): a lane names its own 4-byte source, a wave-instruction fills 256
+        //      consecutive LDS bytes, no VGPR destination, no ds_write, no transposes: the K' and V images cost ~3 vector
+        //      instructions per 256 bytes instead of ~25 (this kernel is bound by VALU issue and the register-path staging
+        //      was a third of its vector instructions).
+        //      K' image: one instruction = 4 rows (64-byte rows); dword slot `sl` of a row holds logical dword
+        //      4 ((sl >> 2) ^ swz) + (sl & 3) -- the chunk swizzle of OperandRows<32> moved to the SOURCE address -- which
+        //      comes from k / kp (head dims), ka (bias columns) or the zero word.  Row groups go round-robin over the waves:
+        //      group & 3 == wave & 3, so a lane's swizzle, source kind and column are constants and a source pointer only
+        //      advances by a per-lane stride.
+        const char* zsrc = reinterpret_cast<const char*>(g_attn_consts);
+        const int hd2 = hd >> 1, a2 = A >> 1;
+        {
+            const int sl = lane & 15, rowin = lane >> 4;
+            const int ld = 4 * ((sl >> 2) ^ ((0 - wave) & 3)) + (sl & 3);
+            const int kind = ld < hd2 ? 0 : (ld < hd2 + a2 ? 1 : 2);
+            const int row0 = 4 * wave + rowin;
+            const long stride = kind == 0 ? 64L * hd : (kind == 1 ? 64L * A : 0L);      // bytes per 32 rows
+            const char* src = kind == 0 ? reinterpret_cast<const char*>(kb) + ((long)row0 * hd + 2 * ld) * 2
+                            : kind == 1 ? reinterpret_cast<const char*>(kab) + ((long)row0 * A + 2 * (ld - hd2)) * 2 : zsrc;
+            int gi = wave;
+            for (; gi < Nqp / 4; gi += NW) { glds4(src, Kimg + gi * 256); src += stride; }
+            // prompt rows, then padding rows (head dims: zero; their bias columns exclude them)
+            if (kind == 0) src = reinterpret_cast<const char*>(kpb) + ((long)(4 * gi + rowin - Nqp) * hd + 2 * ld) * 2;
+            for (; gi < Nkp / 4; gi += NW) {
+                const bool live = 4 * gi < Nqp + n_prompt_rows;                          // wave-uniform
+                glds4((kind == 0 && !live) ? zsrc : src, Kimg + gi * 256);
+                src += stride;
+            }
+        }
+        // V image: one instruction = 8 rows of [16 dv] (32-byte rows): dwords 0 .. hd/2-1 from v / vp, dword hd/2 = (1, 0)
+        // when the softmax denominator rides on the PV product (ONES), the rest zero
+        {
+            const int sl = lane & 7, rowin = lane >> 3;
+            const int row0 = 8 * wave + rowin;
+            const bool fv = sl < hd2;
+            const char* csrc = (ONES && sl == hd2) ? zsrc + 4 : zsrc;
+            const long stride = fv ? 128L * hd : 0L;                                     // bytes per 64 rows
+            const char* src = fv ? reinterpret_cast<const char*>(vb) + ((long)row0 * hd + 2 * sl) * 2 : csrc;
+            int gi = wave;
+            for (; gi < Nqp / 8; gi += NW) { glds4(src, Vt + gi * 256); src += stride; }
+            if (fv) src = reinterpret_cast<const char*>(vpb) + ((long)(8 * gi + rowin - Nqp) * hd + 2 * sl) * 2;
+            for (; gi < Nkp / 8; gi += NW) {
+                const bool live = 8 * gi < Nqp + n_prompt_rows;
+                glds4((fv && !live) ? zsrc : src, Vt + gi * 256);
+                src += stride;
+            }
+        }
+    } else {
     // ---- stage K' ----  (loads of four pieces in flight per thread before the first LDS write)
     {
         constexpr int RPP = 64 * NW / dk4;                   // rows per pass
@@ -492,11 +568,15 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
             }
         }
     }
-    // ---- key classes (classify_logit in common.hpp) ----
-    for (int m = tid; m < Nkp; m += 64 * NW) {
-        // content key: region id; prompt and padding keys: 254 = never masked (padding keys are excluded by their bias)
-        ridk[m] = (uint8_t)((m < d.Nq && MASKED) ? tok_rid[pw * Nqp + m] : (m < d.Nq ? 0 : 254));
     }
+    // ---- key classes (classify_logit in common.hpp) ----
+    if (MASKED) {                                            // (only the masked steps read the classes)
+        for (int m = tid; m < Nkp; m += 64 * NW) {
+            // content key: region id; prompt and padding keys: 254 = never masked (padding keys are excluded by their bias)
+            ridk[m] = (uint8_t)(m < d.Nq ? tok_rid[pw * Nqp + m] : 254);
+        }
+    }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the barrier publishes them
     __syncthreads();
     // Most windows of a shifted block are not cut by the volume boundary: all their content tokens share one region id
     // and the mask is a no-op.  Those windows take the unmasked steps (workgroup-uniform choice).
@@ -519,41 +599,43 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
     // Q' fragments (+ region ids) of a query tile: unconditional loads (common.hpp "Branch-free loads"), issued ONE TILE AHEAD:
     // written as conditional loads in the tile's prologue they were 2-3 dependent memory round trips in front of every
     // ~1 us key loop of the wave.
-    // per-lane piece offsets of query tile 0 and their per-tile strides (the piece's source -- q or the bias one-hots -- is a
-    // lane constant): a tile's addresses are one multiply-add per piece
-    const long to_qa = qa - qb;
-    long q_off0[DKS][2];
-    int q_step[DKS][2];
-    bool q_keep[DKS][2];
+    // a lane's piece source (q, the bias one-hots or -- beyond head_dim + bias columns -- the zero word) is a lane constant: a
+    // running pointer per piece that advances by a per-lane stride from one tile of this wave to the next (64-bit multiply-adds
+    // and keep-masks per tile were ~10 of the ~60 vector instructions a tile spends outside its key loop)
+    const char* qsrc[DKS][2];
+    int q_tile[DKS][2];                                      // bytes from one query tile to the next (0: constant source)
 #pragma unroll
     for (int s = 0; s < DKS; ++s)
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int c4 = 8 * s + 2 * g + hlf;
-            const int ca = min(max(c4 - hd4, 0), a4 - 1);
-            q_off0[s][hlf] = sel(c4 < hd4, (long)(r * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(r * A + 4 * ca));
-            q_step[s][hlf] = sel(c4 < hd4, 16 * hd, 16 * A);
-            q_keep[s][hlf] = c4 < hd4 + a4;
+            const bool fq = c4 < hd4, fa = !fq && c4 < hd4 + a4;
+            const int row0 = QT * wave * 16 + r;
+            qsrc[s][hlf] = fq ? reinterpret_cast<const char*>(qb) + (row0 * hd + 4 * c4) * 2
+                         : fa ? reinterpret_cast<const char*>(qa) + (row0 * A + 4 * (c4 - hd4)) * 2
+                              : reinterpret_cast<const char*>(g_attn_consts) + 8;      // (two zero words)
+            q_tile[s][hlf] = fq ? 32 * hd : (fa ? 32 * A : 0);
         }
+    // loads the Q' fragments of tiles qt_first .. (the pointers stand there) and steps the pointers to this wave's next turn
     auto load_q = [&](int qt_first, bf16x8 (&qfo)[QT][DKS], uint32_t (&rqo)[QT]) {
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
-            const int qt = (qt_first + a < nqt) ? qt_first + a : (qt_first < nqt ? qt_first : 0);
-            const int row = qt * 16 + r;
-            rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, tok_rid[pw * Nqp + min(row, d.Nq - 1)], 0) : 0u;
+            const int ao = (qt_first + a < nqt) ? a : 0;      // an odd tile count: the spare slot shadows the first tile
+            const int row = (qt_first + ao) * 16 + r;
+            rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, (int)ridk[min(row, d.Nq - 1)], 0) : 0u;   // (the key classes hold the same ids)
 #pragma unroll
-            for (int s = 0; s < DKS; ++s) {
-                bf16x4 piece[2];
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf)
-                    piece[hlf] = keep_if(ld4(qb + (q_off0[s][hlf] + (long)(qt * q_step[s][hlf]))), q_keep[s][hlf]);
-                qfo[a][s] = cat44(piece[0], piece[1]);
-            }
+            for (int s = 0; s < DKS; ++s)
+                qfo[a][s] = cat44(*reinterpret_cast<const bf16x4*>(qsrc[s][0] + ao * q_tile[s][0]),
+                                  *reinterpret_cast<const bf16x4*>(qsrc[s][1] + ao * q_tile[s][1]));
         }
+#pragma unroll
+        for (int s = 0; s < DKS; ++s)
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) qsrc[s][hlf] += QT * NW * q_tile[s][hlf];
     };
     bf16x8 qf_next[QT][DKS];
     uint32_t rq_next[QT];
-    load_q(QT * wave, qf_next, rq_next);
+    if (QT * wave < nqt) load_q(QT * wave, qf_next, rq_next);
     for (int qt0 = QT * wave; qt0 < nqt; qt0 += QT * NW) {
         int qrow[QT];
         uint32_t rq[QT];
@@ -569,7 +651,7 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
 #pragma unroll
             for (int s = 0; s < DKS; ++s) qf[a][s] = qf_next[a][s];
         }
-        load_q(qt0 + QT * NW, qf_next, rq_next);              // the next tile's operands travel under this tile's key loop
+        if (qt0 + QT * NW < nqt) load_q(qt0 + QT * NW, qf_next, rq_next);   // the next tile's operands travel under this tile's key loop
         bool first = true;
         auto reset = [&]() {
 #pragma unroll
@@ -672,11 +754,18 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
                 first = false;
             }
             bf16x8 vfr[DVT];
+            if constexpr (DMA) {
+                // V^T fragment by transposing reads of the row-major image: the 16-lane group g passes the addresses of keys
+                // 4g .. 4g+3 (lane 4q+p: row q, dv 4p ..), lane r receives dv = r of those four keys
+                const char* vblk = Vt + (32 * u + 4 * g + (r >> 2)) * 32 + 8 * (r & 3);
+                vfr[0] = cat44(attn_tr_read(vblk), attn_tr_read(vblk + 512));
+            } else {
 #pragma unroll
-            for (int dd = 0; dd < DVT; ++dd) {
-                const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
-                vfr[dd] = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
-                                *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
+                for (int dd = 0; dd < DVT; ++dd) {
+                    const char* vrow = Vt + (size_t)(16 * dd + r) * VROW;
+                    vfr[dd] = cat44(*reinterpret_cast<const bf16x4*>(vrow + (32 * u + 4 * g) * 2),
+                                    *reinterpret_cast<const bf16x4*>(vrow + (32 * u + 16 + 4 * g) * 2));
+                }
             }
 #pragma unroll
             for (int a = 0; a < QT; ++a) {
@@ -709,8 +798,14 @@ __global__ __launch_bounds__(64 * NW, (MASKED && ZREF && !DROP && DKS == 1) ? 8 
             using first_opt = std::integral_constant<bool, ZREF && decltype(opt_c)::value>;
             if (nfull > 0) step(0, std::false_type{}, mask_c, first_opt{});
             else step(0, std::true_type{}, mask_c, first_opt{});
-            for (int u = 1; u < nfull; ++u) step(u, std::false_type{}, mask_c, opt_c);
-            for (int u = nfull > 1 ? nfull : 1; u < npairs; ++u) step(u, std::true_type{}, mask_c, opt_c);
+            // the optimistic steps two at a time (by hand: the pragma is refused around the tested steps' branch): LDS
+            // addresses become immediate offsets, one pointer bump and one loop test per 64 keys
+            int u = 1;
+            if (decltype(opt_c)::value && !decltype(mask_c)::value) {
+                for (; u + 1 < nfull; u += 2) { step(u, std::false_type{}, mask_c, opt_c); step(u + 1, std::false_type{}, mask_c, opt_c); }
+            }
+            for (; u < nfull; ++u) step(u, std::false_type{}, mask_c, opt_c);
+            for (u = nfull > 1 ? nfull : 1; u < npairs; ++u) step(u, std::true_type{}, mask_c, opt_c);
         };
         auto row_sum_of = [&](int a) -> float {
             float ls = lsum[a];
@@ -1023,29 +1118,31 @@ extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const f
     return mivp_check_launch("relbias_aug");
 }
 
-template <int DKS, int DVT, int NW, int QT>
+template <int DKS, int DVT, int NW, int QT, bool DMA>
 static int launch_attn_fwd_cfg(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                                const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
                                hipStream_t st) {
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
-    const size_t lds = (size_t)d->Nkp * krow + (size_t)16 * DVT * vrow + (size_t)d->Nkp;
+    const size_t lds = (size_t)d->Nkp * krow + (DMA ? (size_t)d->Nkp * 32 : (size_t)16 * DVT * vrow) + (size_t)d->Nkp;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
     const bool msk = d->has_mask != 0;
     const bool zref = lse == nullptr && !d->attn_drop_thr;      // forward only (kernel header: ZREF)
     auto kern = d->attn_drop_thr
-        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, true, false, true> : k_win_attn_fwd<DKS, DVT, NW, QT, true, false, false>)
-        : ones ? (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, true>)
-                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false>))
-               : (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, true>)
-                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false>));
+        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, true, false, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, true, false, false, false, DMA>)
+        : ones ? (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, true, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, true, DMA>)
+                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, false, DMA>))
+               : (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, true, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, true, DMA>)
+                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, false, DMA>));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
     }
     const unsigned grid = (unsigned)((long)d->B * d->P * d->heads);
+    static const bool no_remap = getenv("MIVP_ATTN_NO_XCD_REMAP") != nullptr;
+    const int xcd_remap = (!no_remap && grid % 8 == 0 && grid >= 64) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse);
+                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse, xcd_remap);
     return mivp_check_launch("win_attn_fwd");
 }
 
@@ -1055,7 +1152,13 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
                            hipStream_t st) {
     // (NW, QT) = (4, 2) -- two query tiles per wave sharing every K' / V^T fragment -- measures the same as (8, 1) at 7^3
     // windows (87.5 vs 87.2 us per stage-1 block): the kernel is bound by VALU issue, not by the LDS pipe
-    return launch_attn_fwd_cfg<DKS, DVT, 8, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    // one k-step / one value tile (head_dim <= 16: the encoder stages and the last decoder stage): LDS-DMA staged images
+    // (MIVP_ATTN_FWD_REG_STAGING=1 keeps the register-path staging for A/B runs)
+    if constexpr (DKS == 1 && DVT == 1) {
+        static const bool reg_staging = getenv("MIVP_ATTN_FWD_REG_STAGING") != nullptr;
+        if (!reg_staging && d->Nqp % 8 == 0) return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    }
+    return launch_attn_fwd_cfg<DKS, DVT, 8, 1, false>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
 }
 
 // shared by forward and backward dispatch: which (NT, DKS=DVT) instantiation covers this shape

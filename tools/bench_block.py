@@ -16,8 +16,12 @@ if os.environ.get("MIVP_TWO_PASS_ATTN_BWD"):          # A/B: the dq + dkv pair i
     swin_ops.USE_FUSED_ATTN_BWD = False
 stage = sys.argv[1] if len(sys.argv) > 1 else "enc0"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-shift = (3, 3, 3) if (len(sys.argv) > 3 and sys.argv[3] == "shift") else (0, 0, 0)
+shift = (3, 3, 3) if (len(sys.argv) > 3 and "shift" in sys.argv[3:]) else (0, 0, 0)
+fwd_only = "fwdonly" in sys.argv[3:]          # forward-only calls (nothing saved: the zero-reference attention walk), no prompts
+no_prompt = fwd_only or "noprompt" in sys.argv[3:]
 C, heads, dims, npr = STAGES[stage]
+if no_prompt:
+    npr = 0
 B, window = 4, (7, 7, 7)
 gen = torch.Generator().manual_seed(0)
 torch.manual_seed(0)
@@ -30,7 +34,8 @@ dy = torch.randn(B, *dims, C, generator=gen).to(dev, torch.bfloat16)
 for it in range(iters + 2):
     if it == 2:
         torch.cuda.synchronize(); t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
-    y, saved = swin_ops.swin_block_forward(x, prm, w, None, window, shift, save=True)
-    dx, dp, dts = swin_ops.swin_block_backward(saved, w, prm, dy, True, npr > 0)
+    y, saved = swin_ops.swin_block_forward(x, prm, w, None, window, shift, save=not fwd_only)
+    if not fwd_only:
+        dx, dp, dts = swin_ops.swin_block_backward(saved, w, prm, dy, True, npr > 0)
 t1.record(); torch.cuda.synchronize()
 print(stage, "fwd+bwd ms/iter", t0.elapsed_time(t1) / iters)
