@@ -32,6 +32,7 @@
 //   lse_s, del_s [nq] f32, ridq [nq] bytes
 // Every reduction has a fixed order: results are bit-reproducible.
 #include "common.hpp"
+#include <cstdlib>
 
 int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt);
 
@@ -64,6 +65,14 @@ MIVP_DEV f32x4 mfma16k16(bf16x4 a, u32x2 b, f32x4 c) {
 // q, columns 4p..4p+3; lane i receives column i of the four rows (EXEC must be full: callers keep the wave converged)
 MIVP_DEV bf16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+}
+
+// LDS-DMA staging (DMA form of the fused kernel): constant source words and one 4-byte global -> LDS transfer per lane
+// (LDS address = wave-uniform base + 4 * lane), as in the forward kernel (swin_fwd.hip)
+__device__ __attribute__((aligned(16))) unsigned int g_bwd_zero[4] = {0u, 0u, 0u, 0u};
+MIVP_DEV void glds4(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
 constexpr int FUSED_KPW = 4;                                   // key tiles per wave (8 waves: up to 512 keys)
@@ -143,7 +152,10 @@ MIVP_DEV void stage_query_side(const QSide& s, char* Qimg, char* Oimg, float* de
 
 }  // namespace
 
-template <int NW, bool DROP, bool MASKED>
+// ABL: timing ablations (results are WRONG for ABL != 0; selected by MIVP_ATTN_BWD_ABL for cost breakdowns, tools/ab_attn_bwd.sh):
+//   1 no dQ reduce / store   2 no barrier in the tile loop   3 no dS exchange and dQ products   4 at most three key tiles per wave
+//   5 no exponentials / products / conversions (P = dS = S bits)
+template <int NW, bool DROP, bool MASKED, bool DMA = false, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
@@ -169,8 +181,10 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
 
     char* Qimg = smem;
     char* Oimg = Qimg + (size_t)nq * 64;
+    // K^T image [hd][Nkp + 8] of the classic form; DMA form: K ROW-major [Nkp][16] (32-byte rows), the dQ product's A operand
+    // comes out of transposing reads
     char* Kt = Oimg + (size_t)nq * 32;
-    char* exch = Kt + (size_t)hd * KTROW;
+    char* exch = Kt + (DMA ? (size_t)Nkp * 32 : (size_t)hd * KTROW);
     float* dqp = reinterpret_cast<float*>(exch + (size_t)nt * 512);
     float* lse_s = dqp + 2 * NW * 256;
     float* del_s = lse_s + nq;
@@ -198,9 +212,14 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     // this wave's key tiles: K' / V fragments (B operands) from global, once -- issued first, used after the staging
     bf16x8 kf[FUSED_KPW];
     bf16x4 vf[FUSED_KPW];
-    uint32_t kk[FUSED_KPW];                                    // mask operand: live = ((rq | pm) == kk), pm = kk's sign spread
+    // key classes of this lane's key in each owned tile, one BYTE per tile (region id; 255: prompt / padding key, never
+    // masked): live = (class == 255) | (class == query class).  One register instead of one per tile: the masked instantiation
+    // sits at the 128-VGPR limit of two workgroups per CU
+    uint32_t kk4 = 0u;
     f32x4 dkacc[FUSED_KPW], dvacc[FUSED_KPW];
-    f32x2 dsum[FUSED_KPW];                                     // column sums of dS, two partial sums per lane
+    // column sums of dS (gradient of the prompt-token bias), two partial sums per lane, of this wave's LAST key tile only: prompt
+    // tiles are the highest-numbered ones and there are at most eight of them, so a wave owns at most one and it is its last
+    f32x2 dsum = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < FUSED_KPW; ++i) {
         const int kt = wave + NW * i;
@@ -219,11 +238,79 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
         // content key: its region id; prompt and padding keys are never masked (padding keys are excluded by their bias)
         const bool content = krow < d.Nq;
         const uint32_t cls = MASKED ? (uint32_t)tok_rid[pw * Nqp + min(krow, d.Nq - 1)] : 0u;
-        kk[i] = (uint32_t)sel(content, (int)cls, -1);
+        kk4 |= (uint32_t)sel(content, (int)(cls & 0xFFu), 255) << (8 * i);
         dkacc[i] = fzero4();
         dvacc[i] = fzero4();
-        dsum[i] = f32x2{0.f, 0.f};
     }
+    // lse (negated, log2 units: the S accumulators start from it; padding query rows: P = 0) and the query classes
+    const int m0 = min(tid, Nqp - 1);
+    const float lse0 = lseb[m0];
+    const int rid0 = MASKED ? tok_rid[pw * Nqp + m0] : 0;
+    const QSide qs{qb, qa, dob, ob, Nqp, hd, hd4, A, a4, C};
+    if constexpr (DMA) {
+        // ---- LDS-DMA staging (global_load_lds_dword: a lane names its own 4-byte source, a wave-instruction fills 256
+        //      consecutive LDS bytes; no VGPR destination, no ds_write, no register transposes).  Row groups go round-robin
+        //      over the waves, so a lane's swizzle, source kind and column are constants and a pointer only advances by a
+        //      per-lane stride.  The register-path staging was a third of this kernel's vector instructions.
+        static_assert(!DMA || NW == 8, "group strides below assume eight waves");
+        const char* zsrc = reinterpret_cast<const char*>(g_bwd_zero);
+        const int hd2 = hd >> 1, a2 = A >> 1;
+        {   // Q' image: 4 rows (64 B, chunk-swizzled: OperandRows<32>) per instruction; slot sl holds logical dword ld
+            const int sl = lane & 15, rowin = lane >> 4;
+            const int ld = 4 * ((sl >> 2) ^ ((0 - wave) & 3)) + (sl & 3);
+            const int kind = ld < hd2 ? 0 : (ld < hd2 + a2 ? 1 : 2);
+            const int row0 = 4 * wave + rowin;
+            const long stride = kind == 0 ? 64L * hd : (kind == 1 ? 64L * A : 0L);
+            const char* src = kind == 0 ? reinterpret_cast<const char*>(qb) + ((long)row0 * hd + 2 * ld) * 2
+                            : kind == 1 ? reinterpret_cast<const char*>(qa) + ((long)row0 * A + 2 * (ld - hd2)) * 2 : zsrc;
+            int gi = wave;
+            for (; gi < Nqp / 4; gi += NW) { glds4(src, Qimg + gi * 256); src += stride; }
+            for (; gi < nq / 4; gi += NW) glds4(zsrc, Qimg + gi * 256);                  // phantom rows
+        }
+        {   // dO image: 8 rows (32 B, halves swapped in rows 8..15 of every 16: oimg_off) per instruction
+            const int sl = lane & 7, rowin = lane >> 3;
+            const int ld = sl ^ ((wave & 1) << 2);
+            const bool fo = ld < hd2;
+            const long stride = fo ? 128L * C : 0L;                                      // bytes per 64 rows
+            const char* src = fo ? reinterpret_cast<const char*>(dob) + ((long)(8 * wave + rowin) * C + 2 * ld) * 2 : zsrc;
+            int gi = wave;
+            for (; gi < Nqp / 8; gi += NW) { glds4(src, Oimg + gi * 256); src += stride; }
+            for (; gi < nq / 8; gi += NW) glds4(zsrc, Oimg + gi * 256);
+        }
+        {   // K rows [Nkp][16] (head dims | zero): 8 rows per instruction; prompt rows from kp, padding rows zero
+            const int sl = lane & 7, rowin = lane >> 3;
+            const bool fk = sl < hd2;
+            const long stride = fk ? 128L * hd : 0L;
+            const char* src = fk ? reinterpret_cast<const char*>(kb) + ((long)(8 * wave + rowin) * hd + 2 * sl) * 2 : zsrc;
+            int gi = wave;
+            for (; gi < Nqp / 8; gi += NW) { glds4(src, Kt + gi * 256); src += stride; }
+            if (fk) src = reinterpret_cast<const char*>(kpb) + ((long)(8 * gi + rowin - Nqp) * hd + 2 * sl) * 2;
+            for (; gi < Nkp / 8; gi += NW) {
+                const bool live = 8 * gi < Nqp + n_prompt_rows;
+                glds4((fk && !live) ? zsrc : src, Kt + gi * 256);
+                src += stride;
+            }
+        }
+        // delta = sum_j dO * O per query row (negated): plain loads of the two head slices, four lanes per row
+        {
+            const int o_elems = nq * 4;
+            for (int e0 = tid; e0 < o_elems; e0 += 3 * 64 * NW) {
+                bf16x4 gv[3], ov[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) o_piece(qs, min(e0 + 64 * NW * u, o_elems - 1), gv[u], ov[u]);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int e = min(e0 + 64 * NW * u, o_elems - 1);
+                    float part = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part += (float)gv[u][i] * (float)ov[u][i];
+                    part += __shfl_xor(part, 1);
+                    part += __shfl_xor(part, 2);
+                    if ((e & 3) == 0) del_s[e >> 2] = -part;
+                }
+            }
+        }
+    } else {
     // K^T (head dims x keys): four consecutive keys of one 4-channel group, transposed 4x4 in registers.  The image has hd
     // rows: lanes that would read rows hd..15 of the A operand re-read row 0 (row j of A only reaches row j of dQ^T, and
     // rows >= hd are never stored).  Loads here, stores after the query side's loads are out.
@@ -247,14 +334,10 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     };
     bf16x4 kt_in[4];
     kt_load(min(tid, kt_elems - 1), kt_in);
-    // lse (negated, log2 units: the S accumulators start from it; padding query rows: P = 0) and the query classes
-    const int m0 = min(tid, Nqp - 1);
-    const float lse0 = lseb[m0];
-    const int rid0 = MASKED ? tok_rid[pw * Nqp + m0] : 0;
-    const QSide qs{qb, qa, dob, ob, Nqp, hd, hd4, A, a4, C};
     stage_query_side<64 * NW>(qs, Qimg, Oimg, del_s, nq, tid);
     if (tid < kt_elems) kt_store(tid, kt_in);
     for (int e = tid + 64 * NW; e < kt_elems; e += 64 * NW) { kt_load(e, kt_in); kt_store(e, kt_in); }
+    }
     if (tid < nq) {
         const bool ok = tid < Nqp;
         lse_s[tid] = ok ? -lse0 * MIVP_LOG2E : -INFINITY;
@@ -265,6 +348,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
         lse_s[m] = ok ? -lseb[m] * MIVP_LOG2E : -INFINITY;
         ridq[m] = (uint8_t)((ok && m < d.Nq) ? (MASKED ? tok_rid[pw * Nqp + m] : 0) : 255);
     }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the barrier publishes them
     __syncthreads();
     // a shifted block's window that the volume boundary does not cut has ONE region id: its mask is a no-op
     bool cut = false;
@@ -297,10 +381,15 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     const char* o_tr = Oimg + oimg_off(4 * g + (r >> 2), 8 * (r & 3));             // +  512 t : dO^T block for dV^T
     char* ex_wr = exch + exch_off(wave, r, g);                                     // + 4096 i : this wave's slot, as written
     const char* ex_tr = exch + exch_off(wave, 4 * g + (r >> 2), r & 3);            // + 4096 i : ... as read back transposed
-    const char* kt_rd = ktrow + (16 * wave + 4 * g) * 2;                           // +  256 i : K^T columns of key tile i
+    // K^T columns of key tile i (+ 256 i classic; DMA: + 4096 i, a transposing read of the tile's rows 4g .. 4g+3)
+    const char* kt_rd = DMA ? Kt + (16 * wave + 4 * g + (r >> 2)) * 32 + 8 * (r & 3) : ktrow + (16 * wave + 4 * g) * 2;
     float* dqp_wr = dqp + wave * 256 + r * 16 + 4 * g;
     static_assert(NW == 8, "slot strides below assume eight waves");
 
+    // The wave that adds the partials of tile t rotates among the waves that own the FEWEST key tiles (waves nt % NW .. NW-1):
+    // with 26 key tiles the two waves that own four would otherwise also take a turn and every barrier would wait for them
+    const int light0 = nt % NW, nlight = NW - light0;
+    auto reducer_of = [&](int t) { return light0 + t % nlight; };
     // The tile loop is instantiated per (number of key tiles this wave owns, shift mask in effect): its body is then free
     // of branches, so the scheduler interleaves the tiles' MFMA -> exp -> multiply -> convert chains (with a scalar
     // "do I own a fourth tile" test per tile every tile sat in its own basic block behind two s_nop 7).
@@ -308,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
         constexpr int NT = decltype(nt_c)::value;
         constexpr bool CUT = decltype(cut_c)::value;
         for (int t = 0; t < nqt; ++t) {
-            if (t > 0 && wave == ((t - 1) & (NW - 1))) dq_store(t - 1);
+            if (ABL != 1 && t > 0 && wave == reducer_of(t - 1)) dq_store(t - 1);
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
             const f32x4 n4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_rd + 1024 * t);
@@ -326,7 +415,8 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                 const f32x4 s = mfma16(qf, kf[i], l4);
                 const f32x4 dp = mfma16k16(of, vf[i], DROP ? fzero4() : n4);
                 f32x4 pv, ds;
-                const uint32_t pm = (uint32_t)((int32_t)kk[i] >> 31);   // all ones for prompt / padding keys (never masked)
+                const uint32_t kcls = (kk4 >> (8 * i)) & 0xFFu;
+                const bool never = kcls == 255u;               // prompt / padding keys are never masked
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float keep = 1.f;
@@ -337,9 +427,11 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                     }
                     const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
                     float pe, dsv;
-                    if (CUT) {
+                    if (ABL == 5) {
+                        pe = s[j]; dsv = dpe;
+                    } else if (CUT) {
                         // a masked logit is the constant 0 (accumulator value l4[j]): it keeps its P, carries no gradient
-                        const bool live = (rqs[j] | pm) == kk[i];
+                        const bool live = never | (rqs[j] == kcls);
                         pe = __builtin_amdgcn_exp2f(live ? s[j] : l4[j]);
                         dsv = live ? pe * dpe : 0.f;
                     } else {
@@ -349,9 +441,10 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                     pv[j] = DROP ? pe * keep : pe;
                     ds[j] = dsv;
                 }
-                dsum[i] = dsum[i] + (f32x2{ds[0], ds[1]} + f32x2{ds[2], ds[3]});   // only the prompt tiles' sums are used
-                const u32x2 pb = pack4_pk(pv), sb = pack4_pk(ds);
-                *reinterpret_cast<u32x2*>(ex_wr + 4096 * i) = sb;                          // this wave's private slot
+                if (i == NT - 1) dsum = dsum + (f32x2{ds[0], ds[1]} + f32x2{ds[2], ds[3]});   // (used if that tile holds prompt keys)
+                const u32x2 pb = ABL == 5 ? u32x2{__builtin_bit_cast(unsigned, pv[0]), __builtin_bit_cast(unsigned, pv[1])} : pack4_pk(pv);
+                const u32x2 sb = ABL == 5 ? u32x2{__builtin_bit_cast(unsigned, ds[0]), __builtin_bit_cast(unsigned, ds[1])} : pack4_pk(ds);
+                if (ABL != 3) *reinterpret_cast<u32x2*>(ex_wr + 4096 * i) = sb;            // this wave's private slot
                 dkacc[i] = mfma16k16(qt, sb, dkacc[i]);
                 dvacc[i] = mfma16k16(ot, pb, dvacc[i]);
             }
@@ -359,17 +452,18 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
             // (same wave: ordered by the LDS queue), A = K^T columns of the key tile
             f32x4 dqa = fzero4();
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
+            for (int i = 0; i < (ABL == 3 ? 0 : NT); ++i) {
                 const bf16x4 b = tr_read(ex_tr + 4096 * i);
-                const bf16x4 a = *reinterpret_cast<const bf16x4*>(kt_rd + 256 * i);
+                const bf16x4 a = DMA ? tr_read(kt_rd + 4096 * i) : *reinterpret_cast<const bf16x4*>(kt_rd + 256 * i);
                 dqa = mfma16k16(a, b, dqa);
             }
             *reinterpret_cast<f32x4*>(dqp_wr + (t & 1) * NW * 256) = dqa;
-            __syncthreads();
+            if (ABL != 2) __syncthreads();
         }
-        if (wave == ((nqt - 1) & (NW - 1))) dq_store(nqt - 1);    // (a phantom tile stores nothing)
+        if (ABL != 1 && wave == reducer_of(nqt - 1)) dq_store(nqt - 1);      // (a phantom tile stores nothing)
     };
-    const int my_nt = wave < nt ? (nt - wave + NW - 1) / NW : 0;   // scalar
+    int my_nt = wave < nt ? (nt - wave + NW - 1) / NW : 0;         // scalar
+    if (ABL == 4 && my_nt > 3) my_nt = 3;
     auto walk_nt = [&](auto cut_c) {
         switch (my_nt) {
             case 0: walk(std::integral_constant<int, 0>{}, cut_c); break;
@@ -395,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
             }
         } else if (krow < Nqp + d.Npp) {
             const int tp = krow - Nqp;
-            const float dt = col_sum(dsum[i][0] + dsum[i][1]);
+            const float dt = col_sum(dsum[0] + dsum[1]);               // (i is this wave's last tile: see dsum)
             if (4 * g < hd) {
                 *reinterpret_cast<f32x4*>(dkp_part + ((bph * d.Npp + tp) * (long)hd + 4 * g)) = dkacc[i];
                 *reinterpret_cast<f32x4*>(dvp_part + ((bph * d.Npp + tp) * (long)hd + 4 * g)) = dvacc[i];
@@ -554,11 +648,18 @@ extern "C" int mivp_win_attn_bwd_prompt(const MivpSwinDesc* d, const void* q, co
     return mivp_check_launch("win_attn_bwd_prompt");
 }
 
-static size_t fused_lds_bytes(const MivpSwinDesc* d) {
+static size_t fused_lds_bytes(const MivpSwinDesc* d, bool dma) {
     const size_t nq = (size_t)((d->Nqp + 31) / 32 * 2) * 16, nt = d->Nkp / 16;
     const size_t hd = d->C / d->heads;
-    return nq * 64 + nq * 32 + hd * (size_t)(d->Nkp + 8) * 2 + nt * 512 + 2 * 8 * 256 * sizeof(float) + 2 * nq * sizeof(float) +
-           ((nq + 15) & ~(size_t)15);
+    const size_t kimg = dma ? (size_t)d->Nkp * 32 : hd * (size_t)(d->Nkp + 8) * 2;
+    return nq * 64 + nq * 32 + kimg + nt * 512 + 2 * 8 * 256 * sizeof(float) + 2 * nq * sizeof(float) + ((nq + 15) & ~(size_t)15);
+}
+// LDS-DMA staged images unless MIVP_ATTN_BWD_REG_STAGING is set (A/B runs) or they would cost the second workgroup per CU
+static bool fused_use_dma(const MivpSwinDesc* d) {
+    static const bool reg_staging = getenv("MIVP_ATTN_BWD_REG_STAGING") != nullptr;
+    if (reg_staging || d->attn_drop_thr) return false;
+    const size_t a = fused_lds_bytes(d, true), b = fused_lds_bytes(d, false);
+    return a <= 80 * 1024 || b > 80 * 1024;
 }
 
 /* 1 when mivp_win_attn_bwd_fused covers this shape (head_dim <= 16, head_dim + bias columns <= 32, <= 512 keys, LDS fits) */
@@ -568,7 +669,7 @@ extern "C" int mivp_win_attn_bwd_fused_supported(const MivpSwinDesc* d) {
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt) || dks != 1) return 0;
     if (hd > 16 || hd % 4 || d->augp < 4 || d->Nq < 1 || d->Nkp / 16 > 8 * FUSED_KPW) return 0;
-    return fused_lds_bytes(d) <= 160 * 1024 ? 1 : 0;
+    return fused_lds_bytes(d, fused_use_dma(d)) <= 160 * 1024 ? 1 : 0;
 }
 
 extern "C" int mivp_win_attn_bwd_fused(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
@@ -585,11 +686,19 @@ extern "C" int mivp_win_attn_bwd_fused(const MivpSwinDesc* d, const void* q, con
     MIVP_REQUIRE(d->Np == 0 || (kp && vp && dkp_part && dvp_part && dtok_part));
     MIVP_REQUIRE(!d->has_mask || tok_rid);
     if (!mivp_win_attn_bwd_fused_supported(d)) { mivp_set_error("win_attn_bwd_fused: shape outside the fused kernel's range"); return MIVP_EUNSUPPORTED; }
-    const size_t lds = fused_lds_bytes(d);
+    const bool dma = fused_use_dma(d);
+    const size_t lds = fused_lds_bytes(d, dma);
     constexpr int NW = 8;
+    static const int abl = getenv("MIVP_ATTN_BWD_ABL") ? atoi(getenv("MIVP_ATTN_BWD_ABL")) : 0;
     const bool msk = d->has_mask != 0;
     auto kern = d->attn_drop_thr ? (msk ? k_win_attn_bwd_fused<NW, true, true> : k_win_attn_bwd_fused<NW, true, false>)
-                                 : (msk ? k_win_attn_bwd_fused<NW, false, true> : k_win_attn_bwd_fused<NW, false, false>);
+              : (dma && abl == 1) ? (msk ? k_win_attn_bwd_fused<NW, false, true, true, 1> : k_win_attn_bwd_fused<NW, false, false, true, 1>)
+              : (dma && abl == 2) ? (msk ? k_win_attn_bwd_fused<NW, false, true, true, 2> : k_win_attn_bwd_fused<NW, false, false, true, 2>)
+              : (dma && abl == 3) ? (msk ? k_win_attn_bwd_fused<NW, false, true, true, 3> : k_win_attn_bwd_fused<NW, false, false, true, 3>)
+              : (dma && abl == 4) ? (msk ? k_win_attn_bwd_fused<NW, false, true, true, 4> : k_win_attn_bwd_fused<NW, false, false, true, 4>)
+              : (dma && abl == 5) ? (msk ? k_win_attn_bwd_fused<NW, false, true, true, 5> : k_win_attn_bwd_fused<NW, false, false, true, 5>)
+              : dma ? (msk ? k_win_attn_bwd_fused<NW, false, true, true> : k_win_attn_bwd_fused<NW, false, false, true>)
+                    : (msk ? k_win_attn_bwd_fused<NW, false, true> : k_win_attn_bwd_fused<NW, false, false>);
     MIVP_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)d->B * d->P * d->heads)), dim3(64 * NW), lds, (hipStream_t)stream, *d,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kp, (const bf16_t*)vp,
