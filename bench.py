@@ -11,17 +11,19 @@ JSON line.  Workload = BASELINE.json configs[1] (downstream mode, 1-channel 96^3
 window 7x7x7) unless --workload says otherwise.  Inputs are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline            the largest MFMA-shaped kernel (3x3x3 halo-brick conv of the last decoder stage, 144->48 channels at
-                      48^3): algorithmic FLOPs per launch / its mean duration measured with HIP events on the launch stream
-                      inside the timed region, against the dense bf16 MFMA peak.
-  roofline_attention  the window-attention forward of the stage-0 blocks (the kernel family with the largest share of the
-                      step, and the one BASELINE.json's north star sets a target on): algorithmic FLOPs 4 Nq Nk hd per
-                      (window, head) / mean launch duration, as a fraction of the MFMA peak AND of the kernel's real bound,
-                      the VALU / transcendental issue rate (one v_exp_f32 = 8 issue cycles per 64 (query, key) pairs per
-                      SIMD: head_dim 12 gives the matrix pipe 0.19 MFMA-cycles of work per exp-cycle).
-  cpu_baseline        the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample (1 warm-up + 2 timed
-                      training steps, best reported; batch 4 for the prompt-free workloads, batch 1 otherwise), rank 0 at
-                      N=1 only.
+  roofline            the DOMINANT kernel family of the step: the window-attention forward of the stage-0 blocks (the kernel
+                      BASELINE.json's north star sets its MFMA target on).  achieved = algorithmic FLOPs 4 Nq Nk hd per
+                      (window, head) / mean launch duration, measured with HIP events on the launch stream inside the timed
+                      region; peak = dense bf16 MFMA; beside `frac` the fractions of the kernel's real bounds: the
+                      transcendental issue rate (one v_exp_f32 per (query, key) pair) and the whole vector-issue budget of a
+                      32-key step (8 v_exp + 4 v_cvt_pk + 3 MFMA issue slots; costs measured by tools/ubench/valu_rates.hip and
+                      mfma_overlap.hip); traffic = fabric-side bytes per launch from the committed PMC passes
+                      (profiles/r03_traffic.json).
+  roofline_conv       the largest MFMA-shaped kernel (3x3x3 halo-brick conv of the last decoder stage, 144->48 channels at
+                      48^3) against the dense bf16 MFMA peak (this was `roofline` in rounds 1-2).
+  cpu_baseline        the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample (2 warm-up + 5 timed
+                      training steps as BASELINE.md section 3 asks, best and median reported; batch 4 for the prompt-free
+                      workloads, batch 1 otherwise), rank 0 at N=1 only.
 --backend gloo runs the same multi-rank control flow over gloo (ranks may then share one GPU: tests/test_hip_ddp.py).
 """
 import argparse
@@ -52,11 +54,15 @@ def parse():
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steps before the warm-up (>= 10 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="record the whole step in a HIP graph and time replays (train.GraphedStep; single process, dropout 0); "
-                         "the roofline kernels are then timed in a few eager steps AFTER the timed region")
+                    help="record the step in HIP graphs and time replays (train.GraphedStep: with --gpus N one flat gradient "
+                         "all-reduce runs between the forward+backward graph and the optimizer graph; dropout through the device "
+                         "epoch word); the roofline kernels are then timed in a few eager steps AFTER the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("--fp8-attn", action="store_true",
+                    help="BASELINE.json configs[4]'s named arithmetic: E4M3 MFMA window-attention forward in the head_dim < 16 blocks "
+                         "(an experiment that measured slower and less accurate than bf16: off by default, DESIGN.md section 8)")
     return ap.parse_args()
 
 
@@ -65,14 +71,15 @@ def conv_flops(desc):
     return 2.0 * 27 * desc.Cin * desc.Cout * vox
 
 
-def traffic_bytes():
-    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_traffic.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def traffic_bytes(key):
+    """Fabric-side bytes per launch of a roofline kernel from the committed PMC passes of THIS round's build
+    (profiles/r03_traffic.json, tools/pmc_traffic.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate
+    rocprofv3 --pmc runs); None if the file or the entry is absent."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     try:
         with open(path) as f:
-            return float(json.load(f)["conv3d_dec2_6x6"]["hbm_bytes_per_launch"])   # the brick form the model runs
-    except (OSError, KeyError, ValueError):
+            return float(json.load(f)[key]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -89,9 +96,8 @@ def host_cores():
 
 
 def cpu_baseline(conf, size):
-    """The oracle's training step (forward + loss + backward + AdamW) on all usable host cores: one warm-up step, then two
-    timed steps, best of the two (BASELINE.md section 3 asks for 2 + 5; two timed 14-second steps keep the default run
-    inside its few-minute budget -- the spread between them is reported)."""
+    """The oracle's training step (forward + loss + backward + AdamW) on all usable host cores: two warm-up steps, then five
+    timed steps, best and median reported (~11 s per step on the GPU box's 16 cores: ~80 s)."""
     from oracle.unetr_ref import OracleSwinUnetR, random_state
     from oracle.loss_ref import dice_focal_loss
     from oracle import proto_ref
@@ -133,17 +139,20 @@ def cpu_baseline(conf, size):
         loss.backward()
         opt.step()
 
-    step()                                             # warm-up (allocator, thread pool)
+    n_warm, n_timed = 2, 5
+    for _ in range(n_warm):                            # warm-up (allocator, thread pool)
+        step()
     times = []
-    for _ in range(2):
+    for _ in range(n_timed):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
     dt = min(times)
+    med = sorted(times)[len(times) // 2]
     what = "students/teacher step (2 students + teacher, prototype loss)" if ssl else "training step"
-    return {"value": nvol / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"1 warm-up + 2 timed {what}s on a batch of {nvol} volume(s) of {size}^3 (fp32 PyTorch oracle): "
-                      f"best {dt:.1f} s, other {max(times):.1f} s"}
+    return {"value": nvol / dt, "unit": "volumes/s", "cores": cores, "kind": "port", "median_value": nvol / med,
+            "sample": f"{n_warm} warm-up + {n_timed} timed {what}s on a batch of {nvol} volume(s) of {size}^3 (fp32 PyTorch oracle): "
+                      f"best {dt:.1f} s, median {med:.1f} s, worst {max(times):.1f} s"}
 
 
 def attn_flops(desc):
@@ -160,6 +169,15 @@ def attn_exp_bound_seconds(desc, n_cu=256, clock_hz=2.4e9):
     return pairs / 64.0 * 8.0 / (n_cu * 4) / clock_hz
 
 
+def attn_issue_bound_seconds(desc, n_cu=256, clock_hz=2.4e9):
+    """Lower bound from the vector issue port of a SIMD, which every instruction of the key loop shares: per 32 keys x 16
+    queries (512 pairs) a wave issues 8 v_exp_f32 (8.4 cycles each at eight waves per SIMD), 4 v_cvt_pk_bf16_f32 (4.5) and 3
+    MFMAs (each holds the port for 8 of its 16 cycles) = 109 cycles; measured on this part by tools/ubench (the MFMAs of other
+    waves overlap with plain VALU work but not with the port time they hold themselves)."""
+    pairs = float(desc.Nqp) * desc.Nkp * desc.heads * desc.P * desc.B
+    return pairs / 512.0 * (8 * 8.4 + 4 * 4.5 + 3 * 8.0) / (n_cu * 4) / clock_hz
+
+
 def main():
     args = parse()
     import mivp_amd
@@ -167,8 +185,6 @@ def main():
     from mivp_amd.swin_unetr import SwinUnetR
 
     rank, local, world = train.dist_env()
-    if args.graph and (world > 1 or args.dropout > 0):
-        raise SystemExit("--graph records a single-process step without dropout")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = args.device if args.device >= 0 else local
@@ -176,6 +192,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     train.init_distributed(dev, args.backend)
 
+    from mivp_amd import swin_ops
+    if args.fp8_attn:
+        swin_ops.USE_FP8_ATTN_FWD = True
     window = tuple(int(v) for v in args.window.split(","))
     conf, size, batch = train.make_conf(args.workload, window, args.dropout)
     if args.batch:
@@ -188,8 +207,9 @@ def main():
         from mivp_amd.losses import ClusteredPrototypeLoss
         mm = ST.MomentumModel(conf, SwinUnetR).to(dev).train()
         mm.copy_state_dict()
-        student = train.wrap_ddp(mm.net_student, dev_index, gloo=args.backend == "gloo") if world > 1 else mm.net_student
-        if world > 1:
+        # recorded steps synchronise one flat gradient bucket themselves (train.GraphedStep): no DistributedDataParallel
+        student = train.wrap_ddp(mm.net_student, dev_index, gloo=args.backend == "gloo") if (world > 1 and not args.graph) else mm.net_student
+        if world > 1 and not args.graph:
             mm.net_student = student
         net = mm
         opt = train.build_optimizer(mm, conf, capturable=args.graph)
@@ -204,7 +224,7 @@ def main():
         one_step = ST.graphed_students_teacher_step(mm, opt, sched, loss_prt, conf, views) if args.graph else eager_step
     else:
         model = SwinUnetR(conf).to(dev).train()
-        net = train.wrap_ddp(model, dev_index, gloo=args.backend == "gloo") if world > 1 else model
+        net = train.wrap_ddp(model, dev_index, gloo=args.backend == "gloo") if (world > 1 and not args.graph) else model
         opt = train.build_optimizer(net, conf, capturable=args.graph)
         x, y = train.synthetic_batch(conf, batch, size, dev, rank)
 
@@ -258,17 +278,17 @@ def main():
 
     if rank == 0:
         kern_ms, kern_n, kern_desc = _lib.profile_result("roofline")
-        roof = None
+        roof_conv = None
         if kern_n:
             fl = conv_flops(kern_desc)
             achieved = fl / (kern_ms * 1e-3) / 1e12
             kname = "k_conv3d_halo<3>" if _lib.profile_entry("roofline") == "mivp_conv3d_halo_fwd" else "k_conv3d_fwd<3,8,2>"
-            roof = {"kernel": f"{kname} (decoder stage 2 conv_concat: 3x3x3 conv as MFMA GEMM, {kern_desc.Cin}->{kern_desc.Cout} channels, "
-                              f"{kern_desc.dims[0]}x{kern_desc.dims[1]}x{kern_desc.dims[2]} voxels x batch {kern_desc.B})",
-                    "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic_bytes(),
-                    "launches_timed": kern_n, "avg_launch_ms": kern_ms, "flops_per_launch": fl}
-        roof_attn = None
+            roof_conv = {"kernel": f"{kname} (decoder stage 2 conv_concat: 3x3x3 conv as MFMA GEMM, {kern_desc.Cin}->{kern_desc.Cout} channels, "
+                                   f"{kern_desc.dims[0]}x{kern_desc.dims[1]}x{kern_desc.dims[2]} voxels x batch {kern_desc.B})",
+                         "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic_bytes("conv3d_dec2"),
+                         "launches_timed": kern_n, "avg_launch_ms": kern_ms, "flops_per_launch": fl}
+        roof = None
         parts = []
         for key in ("attn", "attn_shift"):
             ms, n, dsc = _lib.profile_result(key)
@@ -278,29 +298,36 @@ def main():
             fl = sum(attn_flops(dsc) * n for _, _, n, dsc in parts)
             secs = sum(ms * 1e-3 * n for _, ms, n, _ in parts)
             bound = sum(attn_exp_bound_seconds(dsc) * n for _, _, n, dsc in parts)
+            issue = sum(attn_issue_bound_seconds(dsc) * n for _, _, n, dsc in parts)
             dsc = parts[0][3]
             achieved = fl / secs / 1e12
-            roof_attn = {"kernel": f"k_win_attn_fwd<1,1,8,...> (stage-0 window attention: {dsc.B * dsc.P} windows x {dsc.heads} heads, "
-                                   f"{dsc.Nq} queries x {dsc.Nq}(+{dsc.Np} prompt) keys, head_dim {dsc.C // dsc.heads})",
-                         "bound": "valu-transcendental issue (MFMA fraction reported beside it)", "achieved": achieved,
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "frac_of_exp_issue_bound": bound / secs,
-                         "avg_launch_ms": {k: ms for k, ms, _, _ in parts}, "launches_timed": {k: n for k, _, n, _ in parts},
-                         "flops_per_launch": attn_flops(dsc)}
+            roof = {"kernel": f"k_win_attn_fwd<1,1,8,...> (stage-0 window attention forward, the dominant kernel family of the step: "
+                              f"{dsc.B * dsc.P} windows x {dsc.heads} heads, {dsc.Nq} queries x {dsc.Nq}(+{dsc.Np} prompt) keys, "
+                              f"head_dim {dsc.C // dsc.heads}; un-shifted and shifted launches together)",
+                    "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                    "binding_resource": "vector issue port (v_exp_f32 + v_cvt_pk + MFMA issue slots), not the matrix pipe: "
+                                        "head_dim 12 gives one v_exp per 96 MFMA FLOP",
+                    "frac_of_exp_issue_bound": bound / secs, "frac_of_vector_issue_bound": issue / secs,
+                    "traffic": traffic_bytes("attn_fwd_stage0"),
+                    "avg_launch_ms": {k: ms for k, ms, _, _ in parts}, "launches_timed": {k: n for k, _, n, _ in parts},
+                    "flops_per_launch": attn_flops(dsc)}
         units = world * batch * args.steps
         line = {
             "metric": "3D volumes/sec (96^3, bf16) training step", "value": units / dt,
             "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" + (" (fp8 e4m3 window-attention forward)" if swin_ops.USE_FP8_ATTN_FWD else ""),
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: swin_unetr {conf.training_mode}, {conf.input_channels}-ch {size}^3, "
                                    f"batch {batch}/GPU, window {window}, enc_prompt={conf.use_encoder_prompting}, "
                                    f"dec_prompt={conf.use_decoder_prompting}, dropout {conf.attn_drop}, random-init weights"
                                    + (", students/teacher step (2 students + EMA teacher, ClusteredPrototypeLoss)" if ssl else ""),
                        "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": float(loss),
                        "backend": args.backend if world > 1 else None,
-                       "launch": "hip-graph replay (whole step recorded once)" if args.graph else "eager (one C-ABI call per kernel)"},
-            "roofline": roof, "roofline_attention": roof_attn,
+                       "launch": ("hip-graph replay (step recorded once" + ("; flat gradient all-reduce between the two graphs)" if world > 1 else ")"))
+                                 if args.graph else "eager (one C-ABI call per kernel)"},
+            "roofline": roof, "roofline_conv": roof_conv,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(conf, size)

@@ -74,6 +74,11 @@ typedef struct MivpSwinDesc {
     /* kept elements are scaled by `scale` = 65536 / (65536 - thr).  Backward re-derives the same mask.     */
     uint32_t attn_drop_thr;   float attn_drop_scale;   uint32_t attn_seed;
     uint32_t proj_drop_thr;   float proj_drop_scale;   uint32_t proj_seed;
+    /* ABI 12: optional DEVICE pointer to one 32-bit epoch word (NULL = none).  Every dropout kernel uses the seeds      */
+    /* seed + epoch[0] * 0x9E3779B1: a recorded HIP graph freezes this descriptor (a kernel argument), so a replay draws */
+    /* a fresh mask by incrementing the word in device memory at the start of the graph; forward and backward kernels of */
+    /* one step read the same value.                                                                                     */
+    const uint32_t* seed_epoch;
 } MivpSwinDesc;
 
 /* Weight fragment images (ABI 9).  The four token kernels below read their GEMM weights as MFMA-fragment-major images:
@@ -420,7 +425,10 @@ int mivp_upcat_bwd(const MivpUpcatDesc* d, const void* dy, void* dx, void* dskip
  * workspace: mivp_dice_focal_ws(B, vol) floats.
  * dlogits may be NULL (ABI 10): the value pass alone; the gradient pass then runs when autograd asks for it,
  * mivp_dice_focal_grad on the SAME workspace (it holds the per-sample Dice sums), scaled by gscale[0] (device pointer to
- * the incoming d total / d loss, NULL = 1) inside the pass instead of a second sweep over the 28 MB gradient.          */
+ * the incoming d total / d loss, NULL = 1) inside the pass instead of a second sweep over the 28 MB gradient.
+ * gamma < 0 (ABI 12): the Dice term ALONE -- MONAI DiceLoss(include_background, to_onehot_y, softmax) of the students /
+ * teacher trainer's supervised modes (modules/students_teacher.py:96-100,190-197): loss[0] = mean_bc dice_bc, no sigmoid /
+ * focal work in either pass.                                                                                          */
 size_t mivp_dice_focal_ws(int32_t B, int64_t vol);
 int mivp_dice_focal(const float* logits, const float* target, int32_t B, int64_t vol, int32_t C,
                     int32_t include_background, float gamma, float* workspace, float* loss, float* dlogits,
@@ -574,6 +582,9 @@ int mivp_store_floats(float* dst, const float* host_values, int32_t n, mivp_stre
 /* EMA teacher update (momentum_model.py:27-36): tensors = device array of {float* teacher, const float* student, int64 n} */
 int mivp_ema_multi(const void* tensors, const void* chunks, int32_t n_chunks, float tau, mivp_stream_t stream);
 int mivp_sizeof_opt(int which);   /* 0: AdamW tensor record, 1: group record, 2: EMA record */
+/* sizeof of the descriptor structs as the LIBRARY was compiled (bindings compare them with their own layout):
+ * 0 MivpSwinDesc, 1 MivpMergeDesc, 2 MivpConvDesc, 3 MivpEmbedDesc, 4 MivpUpcatDesc, 5 MivpOperandDesc, 6 MivpGemmTnDesc */
+int mivp_sizeof_desc(int which);
 
 /* Per-class counts of arg-max(logits) against a label volume (modules/utils.py:14-64 MeanIoU / DiceCoefficient without
  * host round trips): counts int64 [C][3] += (|pred = c and target = c|, |pred = c|, |target = c|); logits f32 [B][vol][C]

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmivp_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -21,7 +21,8 @@ class SwinDesc(C.Structure):
                                    "aug", "augp", "has_mask")] + [("win", i32 * 3), ("q_scale", f32), ("ln_eps", f32),
                                                                   ("attn_drop_thr", C.c_uint32), ("attn_drop_scale", f32),
                                                                   ("attn_seed", C.c_uint32), ("proj_drop_thr", C.c_uint32),
-                                                                  ("proj_drop_scale", f32), ("proj_seed", C.c_uint32)]
+                                                                  ("proj_drop_scale", f32), ("proj_seed", C.c_uint32),
+                                                                  ("seed_epoch", C.c_void_p)]
 
 
 class MergeDesc(C.Structure):

@@ -93,6 +93,13 @@ MIVP_DEV uint32_t drop_hash(uint32_t pair_idx, uint32_t seed) {
     h ^= h >> 13;
     return h * 0xC2B2AE35u;
 }
+// Effective dropout seed of a call: the descriptor's seed, advanced by the device-resident epoch word when the descriptor
+// names one (MivpSwinDesc.seed_epoch, ABI 12).  A recorded HIP graph freezes the descriptor -- a kernel ARGUMENT -- so a
+// replay could only repeat one mask; the epoch word is device MEMORY that the graph itself increments at its start, and the
+// forward and backward kernels of one step read the same value.  NULL (eager calls): the seed as given.
+MIVP_DEV uint32_t drop_seed(uint32_t seed, const uint32_t* __restrict__ epoch) {
+    return epoch ? seed + epoch[0] * 0x9E3779B1u : seed;
+}
 MIVP_DEV bool drop_keep(uint32_t h, int odd, uint32_t thr) { return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= thr); }
 // pair index of attention element (window-head bph, query q, key k): keys k and k^1 share a hash.  All in 32-bit
 // arithmetic (wrap-around only re-uses counters between far-apart windows): attn_row() once per query row, then one add.

@@ -26,7 +26,8 @@ MIVP_DEV Sig sig_all(float z) {
     return g;
 }
 
-template <int C>
+// FOCAL == false: the Dice term alone (MONAI DiceLoss, students_teacher.py:96-100): no sigmoid / log work, focal sum stays 0
+template <int C, bool FOCAL>
 MIVP_DEV void voxel_stats(const float* zz, int cls, int c0, float gamma, float* acc) {
     float mx = -INFINITY;
 #pragma unroll
@@ -42,9 +43,11 @@ MIVP_DEV void voxel_stats(const float* zz, int cls, int c0, float gamma, float* 
             acc[3 * c] += p * t;
             acc[3 * c + 1] += p;
             acc[3 * c + 2] += t;
-            const Sig g = sig_all(zz[c]);
-            const float bce = zz[c] - zz[c] * t - g.ls_pos;
-            acc[3 * LOSS_MAXC] += __expf(gamma * (c == cls ? g.ls_neg : g.ls_pos)) * bce;     // log_sigmoid(-z (2t - 1))
+            if (FOCAL) {
+                const Sig g = sig_all(zz[c]);
+                const float bce = zz[c] - zz[c] * t - g.ls_pos;
+                acc[3 * LOSS_MAXC] += __expf(gamma * (c == cls ? g.ls_neg : g.ls_pos)) * bce;     // log_sigmoid(-z (2t - 1))
+            }
         }
     }
 }
@@ -64,7 +67,7 @@ MIVP_DEV void dice_consts(const float* __restrict__ st, int c0, float wd, float*
     }
 }
 
-template <int C>
+template <int C, bool FOCAL>
 MIVP_DEV void voxel_grad(const float* zz, int cls, int c0, float gamma, float wf, const float* qa, const float* qb, float* gz) {
     float mx = -INFINITY;
 #pragma unroll
@@ -83,7 +86,7 @@ MIVP_DEV void voxel_grad(const float* zz, int cls, int c0, float gamma, float wf
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         float g = p[c] * (q[c] - pq);                                        // through the softmax
-        if (c >= c0) {
+        if (FOCAL && c >= c0) {
             const float t = (c == cls) ? 1.f : 0.f, sg = 2.f * t - 1.f;
             const Sig sv = sig_all(zz[c]);
             const float w = __expf(gamma * (c == cls ? sv.ls_neg : sv.ls_pos));               // log_sigmoid(-z sg)
@@ -98,7 +101,7 @@ MIVP_DEV void voxel_grad(const float* zz, int cls, int c0, float gamma, float wf
 // pass 1: per-block partial sums  [3*C (I, P, T per class) + 1 (focal sum)]  for ONE batch element per block row
 // VEC: four consecutive voxels per thread and iteration through 16-byte loads (vol % 4 == 0): the loads of one iteration
 // are independent, which is what hides the HBM latency of this short grid-stride walk
-template <int C, bool VEC>
+template <int C, bool VEC, bool FOCAL>
 __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restrict__ z, const float* __restrict__ y, long vol,
                                                           int c0, float gamma, int blocks_per_b,
                                                           float* __restrict__ part) {
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restric
                 zb[4 * j] = t4.x; zb[4 * j + 1] = t4.y; zb[4 * j + 2] = t4.z; zb[4 * j + 3] = t4.w;
             }
             const float4 y4 = *reinterpret_cast<const float4*>(y + v);
-            voxel_stats<C>(zb, (int)y4.x, c0, gamma, acc);
-            voxel_stats<C>(zb + C, (int)y4.y, c0, gamma, acc);
-            voxel_stats<C>(zb + 2 * C, (int)y4.z, c0, gamma, acc);
-            voxel_stats<C>(zb + 3 * C, (int)y4.w, c0, gamma, acc);
+            voxel_stats<C, FOCAL>(zb, (int)y4.x, c0, gamma, acc);
+            voxel_stats<C, FOCAL>(zb + C, (int)y4.y, c0, gamma, acc);
+            voxel_stats<C, FOCAL>(zb + 2 * C, (int)y4.z, c0, gamma, acc);
+            voxel_stats<C, FOCAL>(zb + 3 * C, (int)y4.w, c0, gamma, acc);
         }
     } else {
         for (long v = (long)blk * 256 + threadIdx.x; v < vol; v += (long)blocks_per_b * 256) {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void k_dice_focal_stats(const float* __restric
             float zz[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) zz[c] = zv[c];
-            voxel_stats<C>(zz, (int)y[(long)b * vol + v], c0, gamma, acc);
+            voxel_stats<C, FOCAL>(zz, (int)y[(long)b * vol + v], c0, gamma, acc);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,7 +194,7 @@ __global__ void k_dice_focal_finalize(const float* __restrict__ part, int B, int
 }
 
 // pass 2: dz = dL/dz  (f32, same layout as z); VEC as in pass 1 (a group of four voxels never straddles two samples)
-template <int C, bool VEC>
+template <int C, bool VEC, bool FOCAL>
 __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict__ z, const float* __restrict__ y, long vol,
                                                          int B, int c0, float gamma, const float* __restrict__ stats,
                                                          const float* __restrict__ gscale, float* __restrict__ dz) {
@@ -214,10 +217,10 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
             const float4 y4 = *reinterpret_cast<const float4*>(y + i);
             float qa[C], qb[C];
             dice_consts<C>(stats + b * K, c0, wd, qa, qb);
-            voxel_grad<C>(zb, (int)y4.x, c0, gamma, wf, qa, qb, gb);
-            voxel_grad<C>(zb + C, (int)y4.y, c0, gamma, wf, qa, qb, gb + C);
-            voxel_grad<C>(zb + 2 * C, (int)y4.z, c0, gamma, wf, qa, qb, gb + 2 * C);
-            voxel_grad<C>(zb + 3 * C, (int)y4.w, c0, gamma, wf, qa, qb, gb + 3 * C);
+            voxel_grad<C, FOCAL>(zb, (int)y4.x, c0, gamma, wf, qa, qb, gb);
+            voxel_grad<C, FOCAL>(zb + C, (int)y4.y, c0, gamma, wf, qa, qb, gb + C);
+            voxel_grad<C, FOCAL>(zb + 2 * C, (int)y4.z, c0, gamma, wf, qa, qb, gb + 2 * C);
+            voxel_grad<C, FOCAL>(zb + 3 * C, (int)y4.w, c0, gamma, wf, qa, qb, gb + 3 * C);
 #pragma unroll
             for (int j = 0; j < C; ++j)
                 *reinterpret_cast<float4*>(dz + i * C + 4 * j) = make_float4(up * gb[4 * j], up * gb[4 * j + 1], up * gb[4 * j + 2], up * gb[4 * j + 3]);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_dice_focal_grad(const float* __restrict
 #pragma unroll
             for (int c = 0; c < C; ++c) zz[c] = z[i * C + c];
             dice_consts<C>(stats + b * K, c0, wd, qa, qb);
-            voxel_grad<C>(zz, (int)y[i], c0, gamma, wf, qa, qb, gz);
+            voxel_grad<C, FOCAL>(zz, (int)y[i], c0, gamma, wf, qa, qb, gz);
 #pragma unroll
             for (int c = 0; c < C; ++c) dz[i * C + c] = up * gz[c];
         }
@@ -260,13 +263,15 @@ static int dice_focal_run(const float* logits, const float* target, int32_t B, i
         case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;              \
     }
     const bool vec = vol % 4 == 0;                             // 16-byte loads of four voxels
+    const bool focal = gamma >= 0.f;                           // gamma < 0: the Dice term alone (DiceLoss)
     if (do_loss) {
-#define L_STATS(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_stats<CC, true>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, \
-                                                     logits, target, (long)vol, c0, gamma, (int)bpb, part);                    \
-                         else hipLaunchKernelGGL((k_dice_focal_stats<CC, false>), dim3((unsigned)(B * bpb)), dim3(256), 0, st,    \
-                                                 logits, target, (long)vol, c0, gamma, (int)bpb, part); } while (0)
+#define L_STATS1(CC, VV, FF) hipLaunchKernelGGL((k_dice_focal_stats<CC, VV, FF>), dim3((unsigned)(B * bpb)), dim3(256), 0, st, \
+                                                logits, target, (long)vol, c0, gamma, (int)bpb, part)
+#define L_STATS(CC) do { if (focal) { if (vec) L_STATS1(CC, true, true); else L_STATS1(CC, false, true); }                    \
+                         else { if (vec) L_STATS1(CC, true, false); else L_STATS1(CC, false, false); } } while (0)
         LOSS_C_SWITCH(L_STATS)
 #undef L_STATS
+#undef L_STATS1
         int rc = mivp_check_launch("dice_focal_stats");
         if (rc) return rc;
         hipLaunchKernelGGL(k_dice_focal_finalize, dim3(1), dim3(1024), 0, st, part, (int)B, (int)bpb, (long)vol, (int)C, c0, stats, loss);
@@ -276,12 +281,13 @@ static int dice_focal_run(const float* logits, const float* target, int32_t B, i
     if (!dlogits) return MIVP_OK;
     const long total = vec ? (long)B * vol / 4 : (long)B * vol;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define L_GRAD(CC) do { if (vec) hipLaunchKernelGGL((k_dice_focal_grad<CC, true>), dim3(grid), dim3(256), 0, st, logits, target, \
-                                                    (long)vol, (int)B, c0, gamma, stats, gscale, dlogits);                    \
-                        else hipLaunchKernelGGL((k_dice_focal_grad<CC, false>), dim3(grid), dim3(256), 0, st, logits, target,   \
-                                                (long)vol, (int)B, c0, gamma, stats, gscale, dlogits); } while (0)
+#define L_GRAD1(CC, VV, FF) hipLaunchKernelGGL((k_dice_focal_grad<CC, VV, FF>), dim3(grid), dim3(256), 0, st, logits, target, \
+                                               (long)vol, (int)B, c0, gamma, stats, gscale, dlogits)
+#define L_GRAD(CC) do { if (focal) { if (vec) L_GRAD1(CC, true, true); else L_GRAD1(CC, false, true); }                        \
+                        else { if (vec) L_GRAD1(CC, true, false); else L_GRAD1(CC, false, false); } } while (0)
     LOSS_C_SWITCH(L_GRAD)
 #undef L_GRAD
+#undef L_GRAD1
 #undef LOSS_C_SWITCH
     return mivp_check_launch("dice_focal_grad");
 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 3 : 4)) void k_swin_
                 if (ti.live) st4(d_t1 + ti.tt * (long)C + n0, out);      // the residual branch sees dt1 unmasked
                 if (d.proj_drop_thr) {
                     const uint32_t pi = (uint32_t)((ti.tt * C + n0) >> 1);
-                    const uint32_t h0 = drop_hash(pi, d.proj_seed), h1 = drop_hash(pi + 1, d.proj_seed);
+                    const uint32_t h0 = drop_hash(pi, drop_seed(d.proj_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.proj_seed, d.seed_epoch));
                     v[0] = drop_keep(h0, 0, d.proj_drop_thr) ? v[0] * d.proj_drop_scale : 0.f;
                     v[1] = drop_keep(h0, 1, d.proj_drop_thr) ? v[1] * d.proj_drop_scale : 0.f;
                     v[2] = drop_keep(h1, 0, d.proj_drop_thr) ? v[2] * d.proj_drop_scale : 0.f;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
                     }
                     if (DROP) {                              // dP = dropout'(dO V^T): same mask and scale as the forward
                         const uint32_t pi = attn_pair(drow, 16 * (t0 + lt) + 4 * g);
-                        const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
+                        const uint32_t h0 = drop_hash(pi, drop_seed(d.attn_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.attn_seed, d.seed_epoch));
                         dp[0] = drop_keep(h0, 0, d.attn_drop_thr) ? dp[0] * d.attn_drop_scale : 0.f;
                         dp[1] = drop_keep(h0, 1, d.attn_drop_thr) ? dp[1] * d.attn_drop_scale : 0.f;
                         dp[2] = drop_keep(h1, 0, d.attn_drop_thr) ? dp[2] * d.attn_drop_scale : 0.f;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                         for (int j = 0; j < 4; ++j) {
                             float keep = 1.f;
                             if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
-                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
                                 keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                             }
                             float p, dsv;
@@ -1250,14 +1250,14 @@ __global__ __launch_bounds__(256) void k_dropout_masks(MivpSwinDesc d, uint8_t* 
             const long rest = e / d.Nkp;
             const int q = (int)(rest % d.Nqp);
             const long bph = rest / d.Nqp;
-            const uint32_t h = drop_hash(attn_pair(attn_row(bph, q, d.Nqp, d.Nkp), k), d.attn_seed);
+            const uint32_t h = drop_hash(attn_pair(attn_row(bph, q, d.Nqp, d.Nkp), k), drop_seed(d.attn_seed, d.seed_epoch));
             attn_keep[e] = (d.attn_drop_thr == 0 || drop_keep(h, k & 1, d.attn_drop_thr)) ? 1 : 0;
         }
     }
     if (proj_keep) {
         const long total = (long)d.B * d.P * d.Nqp * d.C;
         for (long e = gtid; e < total; e += stride) {
-            const uint32_t h = drop_hash((uint32_t)(e >> 1), d.proj_seed);
+            const uint32_t h = drop_hash((uint32_t)(e >> 1), drop_seed(d.proj_seed, d.seed_epoch));
             proj_keep[e] = (d.proj_drop_thr == 0 || drop_keep(h, (int)(e & 1), d.proj_drop_thr)) ? 1 : 0;
         }
     }

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                     float keep = 1.f;
                     if (DROP) {                                // element (query 16t + 4g + j, key 16 kt + r)
                         const int krow = 16 * (wave + NW * i) + r;
-                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
                         keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                     }
                     const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 4 : 8) void k_win_attn_bwd_prompt(
             float keep = 1.f;
             if (DROP) {
                 const int krow = Nqp + trow;
-                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), d.attn_seed);
+                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
                 keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
             }
             const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];

@@ -599,11 +599,17 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
     // Q' fragments (+ region ids) of a query tile: unconditional loads (common.hpp "Branch-free loads"), issued ONE TILE AHEAD:
     // written as conditional loads in the tile's prologue they were 2-3 dependent memory round trips in front of every
     // ~1 us key loop of the wave.
-    // a lane's piece source (q, the bias one-hots or -- beyond head_dim + bias columns -- the zero word) is a lane constant: a
-    // running pointer per piece that advances by a per-lane stride from one tile of this wave to the next (64-bit multiply-adds
-    // and keep-masks per tile were ~10 of the ~60 vector instructions a tile spends outside its key loop)
+    // DMA form: a lane's piece source (q, the bias one-hots or -- beyond head_dim + bias columns -- the zero word) is a lane
+    // constant: a running pointer per piece that advances by a per-lane stride from one tile of this wave to the next (64-bit
+    // multiply-adds and keep-masks per tile were ~10 of the ~60 vector instructions a tile spends outside its key loop).
+    // Classic form (kept for the masked forward-only kernel, which fits 64 VGPRs -- four workgroups per CU -- only with the
+    // round-2 addressing): per-lane piece offsets of query tile 0 and per-tile strides, one multiply-add per piece and tile.
     const char* qsrc[DKS][2];
     int q_tile[DKS][2];                                      // bytes from one query tile to the next (0: constant source)
+    const long to_qa = qa - qb;
+    long q_off0[DKS][2];
+    int q_step[DKS][2];
+    bool q_keep[DKS][2];
 #pragma unroll
     for (int s = 0; s < DKS; ++s)
 #pragma unroll
@@ -615,27 +621,48 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                          : fa ? reinterpret_cast<const char*>(qa) + (row0 * A + 4 * (c4 - hd4)) * 2
                               : reinterpret_cast<const char*>(g_attn_consts) + 8;      // (two zero words)
             q_tile[s][hlf] = fq ? 32 * hd : (fa ? 32 * A : 0);
+            const int ca = min(max(c4 - hd4, 0), a4 - 1);
+            q_off0[s][hlf] = sel(c4 < hd4, (long)(r * hd + 4 * min(c4, hd4 - 1)), to_qa + (long)(r * A + 4 * ca));
+            q_step[s][hlf] = sel(c4 < hd4, 16 * hd, 16 * A);
+            q_keep[s][hlf] = c4 < hd4 + a4;
         }
-    // loads the Q' fragments of tiles qt_first .. (the pointers stand there) and steps the pointers to this wave's next turn
+    // loads the Q' fragments of tiles qt_first .. ; DMA form: the pointers stand there and step to this wave's next turn
     auto load_q = [&](int qt_first, bf16x8 (&qfo)[QT][DKS], uint32_t (&rqo)[QT]) {
+        if constexpr (DMA) {
 #pragma unroll
-        for (int a = 0; a < QT; ++a) {
-            const int ao = (qt_first + a < nqt) ? a : 0;      // an odd tile count: the spare slot shadows the first tile
-            const int row = (qt_first + ao) * 16 + r;
-            rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, (int)ridk[min(row, d.Nq - 1)], 0) : 0u;   // (the key classes hold the same ids)
+            for (int a = 0; a < QT; ++a) {
+                const int ao = (qt_first + a < nqt) ? a : 0;  // an odd tile count: the spare slot shadows the first tile
+                const int row = (qt_first + ao) * 16 + r;
+                rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, (int)ridk[min(row, d.Nq - 1)], 0) : 0u;   // (the key classes hold the same ids)
+#pragma unroll
+                for (int s = 0; s < DKS; ++s)
+                    qfo[a][s] = cat44(*reinterpret_cast<const bf16x4*>(qsrc[s][0] + ao * q_tile[s][0]),
+                                      *reinterpret_cast<const bf16x4*>(qsrc[s][1] + ao * q_tile[s][1]));
+            }
 #pragma unroll
             for (int s = 0; s < DKS; ++s)
-                qfo[a][s] = cat44(*reinterpret_cast<const bf16x4*>(qsrc[s][0] + ao * q_tile[s][0]),
-                                  *reinterpret_cast<const bf16x4*>(qsrc[s][1] + ao * q_tile[s][1]));
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) qsrc[s][hlf] += QT * NW * q_tile[s][hlf];
+        } else {
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                const int qt = (qt_first + a < nqt) ? qt_first + a : (qt_first < nqt ? qt_first : 0);
+                const int row = qt * 16 + r;
+                rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, tok_rid[pw * Nqp + min(row, d.Nq - 1)], 0) : 0u;
+#pragma unroll
+                for (int s = 0; s < DKS; ++s) {
+                    bf16x4 piece[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf)
+                        piece[hlf] = keep_if(ld4(qb + (q_off0[s][hlf] + (long)(qt * q_step[s][hlf]))), q_keep[s][hlf]);
+                    qfo[a][s] = cat44(piece[0], piece[1]);
+                }
+            }
         }
-#pragma unroll
-        for (int s = 0; s < DKS; ++s)
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) qsrc[s][hlf] += QT * NW * q_tile[s][hlf];
     };
     bf16x8 qf_next[QT][DKS];
     uint32_t rq_next[QT];
-    if (QT * wave < nqt) load_q(QT * wave, qf_next, rq_next);
+    if (!DMA || QT * wave < nqt) load_q(QT * wave, qf_next, rq_next);
     for (int qt0 = QT * wave; qt0 < nqt; qt0 += QT * NW) {
         int qrow[QT];
         uint32_t rq[QT];
@@ -651,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
 #pragma unroll
             for (int s = 0; s < DKS; ++s) qf[a][s] = qf_next[a][s];
         }
-        if (qt0 + QT * NW < nqt) load_q(qt0 + QT * NW, qf_next, rq_next);   // the next tile's operands travel under this tile's key loop
+        if (!DMA || qt0 + QT * NW < nqt) load_q(qt0 + QT * NW, qf_next, rq_next);   // the next tile's operands travel under this tile's key loop
         bool first = true;
         auto reset = [&]() {
 #pragma unroll
@@ -780,7 +807,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                     for (int hh = 0; hh < 2; ++hh) {
                         const int key0 = 16 * (2 * u + hh) + 4 * g;
                         const uint32_t pi = attn_pair(drow[a], key0);
-                        const uint32_t h0 = drop_hash(pi, d.attn_seed), h1 = drop_hash(pi + 1, d.attn_seed);
+                        const uint32_t h0 = drop_hash(pi, drop_seed(d.attn_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.attn_seed, d.seed_epoch));
                         sv[a][hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[a][hh][0] : 0.f;
                         sv[a][hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[a][hh][1] : 0.f;
                         sv[a][hh][2] = drop_keep(h1, 0, d.attn_drop_thr) ? sv[a][hh][2] : 0.f;
@@ -948,7 +975,7 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 4 : 5)) void k_swin_
             f32x4 keep = {1.f, 1.f, 1.f, 1.f};
             if (d.proj_drop_thr) {                           // proj dropout: on proj(o) + b, before the residual
                 const uint32_t pi = (uint32_t)((tt * C + n0) >> 1);
-                const uint32_t h0 = drop_hash(pi, d.proj_seed), h1 = drop_hash(pi + 1, d.proj_seed);
+                const uint32_t h0 = drop_hash(pi, drop_seed(d.proj_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.proj_seed, d.seed_epoch));
                 keep[0] = drop_keep(h0, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
                 keep[1] = drop_keep(h0, 1, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
                 keep[2] = drop_keep(h1, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
@@ -1156,7 +1183,11 @@ static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, 
     // (MIVP_ATTN_FWD_REG_STAGING=1 keeps the register-path staging for A/B runs)
     if constexpr (DKS == 1 && DVT == 1) {
         static const bool reg_staging = getenv("MIVP_ATTN_FWD_REG_STAGING") != nullptr;
-        if (!reg_staging && d->Nqp % 8 == 0) return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+        // (the masked kernels need ~72 VGPRs in this form: three workgroups per CU; round 2's classic masked forward-only
+        //  kernel squeezed into 64 without scratch and measured 148 us per stage-0 launch against 153 here, the unmasked
+        //  ones gain 5 %)
+        if (!reg_staging && d->Nqp % 8 == 0)
+            return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
     }
     return launch_attn_fwd_cfg<DKS, DVT, 8, 1, false>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
 }

@@ -20,7 +20,7 @@ int mivp_check_launch(const char* what) {
     return MIVP_OK;
 }
 
-extern "C" int mivp_abi_version(void) { return 11; }
+extern "C" int mivp_abi_version(void) { return 12; }
 extern "C" const char* mivp_last_error(void) { return g_err; }
 
 __global__ void k_cast_f32_bf16(const float* __restrict__ in, long n, bf16_t* __restrict__ out) {

@@ -65,16 +65,23 @@ def flush_counters():
 
 # ``torch.optim.AdamW(fused=True)`` (and any other optimizer that updates parameters through an op without an
 # in-place-version bump) changes a parameter's values while ``p._version`` and ``p.data_ptr()`` stay the same, so the
-# version counter alone cannot tell a cache that its packed copies are stale.  Every optimizer step therefore advances a
-# process-wide epoch (a post-step hook registered for ALL torch optimizers, plus our own fused optimizer), and the stamp
-# of a parameter that can be stepped (``requires_grad``) carries it.  Frozen parameters keep version + pointer only, so the
-# frozen backbone of ``--training-mode downstream`` is packed once.
+# version counter alone cannot tell a cache that its packed copies are stale.  Two process-wide counters close that gap:
+#   * ``_param_epoch``: advanced by every optimizer step (a post-step hook registered for ALL torch optimizers, plus our own
+#     fused optimizer); part of the stamp of parameters that can be stepped (``requires_grad``).  Frozen parameters do not
+#     carry it, so the frozen backbone of ``--training-mode downstream`` is packed once;
+#   * ``_raw_epoch``: advanced by ``invalidate_weight_caches()`` only -- raw kernels that write parameters behind autograd's
+#     back (the EMA teacher update, a replayed graph) -- and part of EVERY stamp: the teacher is frozen
+#     (``requires_grad=False`` after ``copy_state_dict``, students_teacher.py:136) yet rewritten every step, and round 2's
+#     cache kept serving its first packed weights (an effective tau of 1).
 _param_epoch = [0]
+_raw_epoch = [0]
 
 
 def invalidate_weight_caches():
-    """Call after changing trainable parameters behind autograd's back (``p.data`` arithmetic through raw kernels)."""
+    """Call after changing parameters behind autograd's back (``p.data`` arithmetic through raw kernels, graph replays):
+    every packed copy, of trainable and of frozen parameters, is rebuilt at its next use."""
     _param_epoch[0] += 1
+    _raw_epoch[0] += 1
 
 
 def _optimizer_post_step(optimizer, args, kwargs):
@@ -86,6 +93,21 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 _register_post_step(_optimizer_post_step)
 
 
+_dropout_epochs = {}
+
+
+def dropout_epoch(device) -> torch.Tensor:
+    """The device's dropout epoch word (int32 [1]): recorded steps increment it, the dropout kernels of a recording fold it
+    into their seeds (mivp.h ``MivpSwinDesc.seed_epoch``)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = str(device)
+    if key not in _dropout_epochs:
+        _dropout_epochs[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _dropout_epochs[key]
+
+
 class WeightCache:
     """key -> kernel-ready tensors, rebuilt when any source parameter changed."""
 
@@ -94,8 +116,8 @@ class WeightCache:
 
     @staticmethod
     def _stamp(params):
-        ep = _param_epoch[0]
-        return tuple((p._version, p.data_ptr(), str(p.device), ep if p.requires_grad else -1)
+        ep, raw = _param_epoch[0], _raw_epoch[0]
+        return tuple((p._version, p.data_ptr(), str(p.device), ep if p.requires_grad else -1, raw)
                      for p in params if p is not None)
 
     def get(self, key, params, builder):
@@ -394,11 +416,12 @@ def swin_block(block, x, prompt: Optional[torch.Tensor]):
     if block.training and (p_attn > 0 or p_proj > 0):
         # counter-hash dropout inside the kernels; the two seeds come from torch's CPU generator, so
         # torch.manual_seed() reproduces a run (the random STREAM differs from nn.Dropout's by construction)
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("attention / projection dropout draws its seeds on the host per call: a recorded graph would "
-                               "replay ONE mask for ever -- train.GraphedStep needs attn_drop = proj_drop = 0")
+        # Under a graph recording the two host-drawn seeds are frozen with the descriptor (a kernel argument); the kernels
+        # then fold a device-resident epoch word into them, which the recorded step increments at its start
+        # (train.GraphedStep): every replay draws fresh masks, forward and backward of one step agree.
         seeds = torch.randint(0, 2 ** 31 - 1, (2,))
-        dropout = (p_attn, p_proj, int(seeds[0]), int(seeds[1]))
+        epoch = dropout_epoch(x.device).data_ptr() if torch.cuda.is_current_stream_capturing() else None
+        dropout = (p_attn, p_proj, int(seeds[0]), int(seeds[1]), epoch)
     if train_w:
         t_h, t_w, t_d = content_tables(pe)        # same for the content tables [heads, 2w-1]
         return _SwinBlockTrainFn.apply(x, prompt, ts, t_h, t_w, t_d, w, block.window_size, block.shift_size, dropout,

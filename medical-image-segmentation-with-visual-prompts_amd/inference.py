@@ -25,14 +25,32 @@ def window_grid(image_size: Sequence[int], roi: Sequence[int]) -> Tuple[List[sli
     return slc, stride, count
 
 
-def sliding_windows(x: torch.Tensor, roi: Sequence[int]) -> torch.Tensor:
+def sliding_window_view(x: torch.Tensor, roi: Sequence[int]) -> torch.Tensor:
     """``x [1, C, H, W, D]`` -> ``[N, C, r0, r1, r2]`` in the reference's window order (segmentation.py:242-253)."""
     if x.shape[0] != 1:
         raise ValueError("the reference's test() unfolds one volume at a time (it squeezes the batch axis)")
     slc, stride, _ = window_grid(x.shape[2:], roi)
     a = x[:, :, slc[0], slc[1], slc[2]]
     u = a.unfold(2, roi[0], stride[0]).unfold(3, roi[1], stride[1]).unfold(4, roi[2], stride[2])
-    return u.flatten(2, 4).permute(2, 1, 0, 3, 4, 5).squeeze(2).contiguous()
+    # a VIEW over the volume ([n0, n1, n2] windows of [C, roi]): with stride roi / 2 the materialised windows are ~8x the
+    # volume (the reference keeps them on the CPU and moves ten at a time); ``window_batch`` copies one sub-batch
+    return u.squeeze(0).permute(1, 2, 3, 0, 4, 5, 6)
+
+
+def sliding_windows(x: torch.Tensor, roi: Sequence[int]) -> torch.Tensor:
+    """All windows materialised, ``[N, C, roi]`` in the reference's flatten order (tests; small volumes)."""
+    v = sliding_window_view(x, roi)
+    return v.reshape(-1, *v.shape[3:]).contiguous()
+
+
+def window_batch(win_view: torch.Tensor, begin: int, end: int) -> torch.Tensor:
+    """Windows ``begin .. end`` (row-major over the window grid, the reference's flatten order) as one contiguous batch."""
+    flat = win_view.reshape(-1, *win_view.shape[3:]) if win_view.is_contiguous() else None
+    if flat is not None:
+        return flat[begin:end]
+    n0, n1, n2 = win_view.shape[:3]
+    idx = torch.arange(begin, min(end, n0 * n1 * n2), device=win_view.device)
+    return win_view[idx // (n1 * n2), (idx // n2) % n1, idx % n2].contiguous()
 
 
 class SegMetrics:
@@ -81,12 +99,13 @@ def test_volume(model, x: torch.Tensor, seg: torch.Tensor, roi: Sequence[int], n
     the volume's windows.  ``x [1, C, H, W, D]``, ``seg [1, 1, H, W, D]`` (already mapped to class indices).  Returns
     (mean IoU, mean Dice) of this volume."""
     dev = x.device
-    xw = sliding_windows(x, roi)
-    sw = sliding_windows(seg, roi)
+    xw = sliding_window_view(x, roi)
+    sw = sliding_window_view(seg, roi)
     m = SegMetrics(num_classes, dev)
-    for i in range(0, xw.shape[0], sub_batch):
-        out = model(xw[i:i + sub_batch])["downstream"]
-        m.update(out, sw[i:i + sub_batch])
+    n = xw.shape[0] * xw.shape[1] * xw.shape[2]
+    for i in range(0, n, sub_batch):
+        out = model(window_batch(xw, i, i + sub_batch))["downstream"]
+        m.update(out, window_batch(sw, i, i + sub_batch))
     return m.compute()
 
 

@@ -7,7 +7,8 @@
   hundred rows at the reference's sizes) with stock PyTorch GPU tensor ops.
 * ``dice_focal_loss``         -- lives in train.py (fused HIP kernel, csrc/loss.hip).
 * ``dice_loss``               -- MONAI ``DiceLoss(include_background, to_onehot_y=True, softmax=True)`` as documented
-  (students_teacher.py:96-100); MONAI is absent from the image: parity unpinned, restated in oracle/loss_ref.py.
+  (students_teacher.py:96-100); the Dice-focal kernels without the focal term; MONAI is absent from the image: parity
+  unpinned, restated in oracle/loss_ref.py::dice_loss.
 """
 from __future__ import annotations
 
@@ -260,14 +261,17 @@ class ClusteredPrototypeLoss(torch.nn.Module):
 
 
 def dice_loss(logits: torch.Tensor, target: torch.Tensor, include_background: bool = True) -> torch.Tensor:
-    """MONAI ``DiceLoss(include_background, to_onehot_y=True, softmax=True)`` (students_teacher.py:96-100): per (batch,
-    class) ``1 - (2 sum(p t) + 1e-5) / (sum(p) + sum(t) + 1e-5)``, mean.  Parity unpinned (MONAI absent)."""
-    ncls = logits.shape[1]
-    onehot = F.one_hot(target[:, 0].long(), ncls).permute(0, 4, 1, 2, 3).to(torch.float32)
-    prob = logits.float().softmax(dim=1)
-    if not include_background:
-        onehot, prob = onehot[:, 1:], prob[:, 1:]
-    dims = (2, 3, 4)
-    inter = (prob * onehot).sum(dims)
-    denom = prob.sum(dims) + onehot.sum(dims)
-    return (1.0 - (2.0 * inter + 1e-5) / (denom + 1e-5)).mean()
+    """MONAI ``DiceLoss(include_background, to_onehot_y=True, softmax=True)`` (students_teacher.py:96-100, used at :190-197):
+    per (batch, class) ``1 - (2 sum(p t) + 1e-5) / (sum(p) + sum(t) + 1e-5)``, mean.  Parity unpinned (MONAI absent; restated
+    in oracle/loss_ref.py::dice_loss).  On the device this is the Dice-focal statistics / gradient kernel pair without the
+    focal term (csrc/loss.hip, ``gamma < 0``): two streaming passes over the logits, no softmax / one-hot tensors."""
+    from .train import _DiceFocalFn
+    if not logits.is_cuda:
+        raise RuntimeError("mivp_amd.losses.dice_loss runs on the GPU (the CPU restatement is oracle/loss_ref.py)")
+    if logits.shape[1] > 8:
+        raise RuntimeError("dice_loss: at most 8 classes (csrc/loss.hip)")
+    base = logits.permute(0, 2, 3, 4, 1)
+    if base.dtype != torch.float32 or not base.is_contiguous():
+        base = base.float().contiguous()                    # (the HIP model's logits already are channels-last f32 storage)
+    tgt = target.to(torch.float32).contiguous()
+    return _DiceFocalFn.apply(base, tgt, include_background, -1.0)

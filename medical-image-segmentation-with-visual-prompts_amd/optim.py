@@ -63,6 +63,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._steps = {id(p): int(float(st["step"])) for p, st in self.state.items() if "step" in st}
         self._plan = None
+        self._hyper_fast = None
 
     def _build(self, entries):
         dev = entries[0][1].device
@@ -81,17 +82,33 @@ class FusedAdamW(torch.optim.Optimizer):
         """Advance the step counts of ``stepping`` (ids of the parameters that step now) and return this step's
         [groups][8] table: lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 0."""
         hyper = np.zeros((len(self.param_groups), 8), np.float32)
+        # per group: the ids that step and their common count, kept between calls while the stepping set is the same (a
+        # replayed step must not walk ~230 parameters in Python: that was 0.3 ms of host time per step)
+        key = (id(stepping) if isinstance(stepping, frozenset) else None, len(stepping))
+        fast = getattr(self, "_hyper_fast", None)
+        if fast is None or fast[0] != key or key[0] is None:
+            groups = []
+            for gi, group in enumerate(self.param_groups):
+                ids = [id(p) for p in group["params"] if id(p) in stepping]
+                counts = {self._steps.get(i, 0) for i in ids}
+                if len(counts) > 1:
+                    # torch.optim.AdamW corrects the bias per PARAMETER; the kernel's table holds one pair per group
+                    raise RuntimeError(
+                        f"FusedAdamW: parameters of group {gi} that step together have different step counts ({sorted(counts)}: a "
+                        "parameter that got its first gradient later, or a resumed state with mixed counts); put them in "
+                        "separate groups")
+                groups.append([ids, counts.pop() if counts else 0])
+            fast = (key, groups)
+            self._hyper_fast = fast if key[0] is not None else None
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            step_no = None
-            for p in group["params"]:
-                if id(p) not in stepping:
-                    continue
-                n = self._steps.get(id(p), 0) + 1
-                self._steps[id(p)] = n
+            ids, n = fast[1][gi]
+            step_no = 1.0
+            if ids:
+                n += 1
+                fast[1][gi][1] = n
+                self._steps.update(dict.fromkeys(ids, n))
                 step_no = float(n)
-            if step_no is None:
-                step_no = 1.0
             # all parameters of a group that receive gradients step together (as in the reference's trainers)
             hyper[gi] = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** step_no,
                          math.sqrt(1.0 - b2 ** step_no), 0.0)
@@ -139,7 +156,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if capturing:
             # the recording is not a step: counts and the device table are advanced by advance() before each replay
             hyper = None
-            self._graph_params = stepping
+            self._graph_params = frozenset(stepping)
             if self._hyper_dev is None:
                 raise RuntimeError("FusedAdamW: run at least one eager step before recording (state and tables are built there)")
         else:

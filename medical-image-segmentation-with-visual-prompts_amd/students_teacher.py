@@ -77,10 +77,10 @@ def synthetic_views(conf: Namespace, batch: int, size: int, device, rank: int = 
     return dict(image=to(x_t), coord=to(coord_t), image_st=[to(t) for t in x_s], coord_st=[to(t) for t in coord_s], mask_st_0=to(y0))
 
 
-def students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: ClusteredPrototypeLoss, conf: Namespace,
-                          batch: dict, jitters=None) -> torch.Tensor:
-    """One iteration of students_teacher.py:150-207: EMA teacher update, students + teacher forward, prototype loss
-    (+ Dice on student 0 in the supervised modes with real labels), backward, optimizer and per-step scheduler."""
+def students_teacher_forward_backward(model: MomentumModel, optimizer, loss_prt: ClusteredPrototypeLoss, conf: Namespace,
+                                      batch: dict, jitters=None) -> torch.Tensor:
+    """students_teacher.py:150-205 up to (not including) the optimizer step: EMA teacher update, students + teacher forward,
+    prototype loss (+ Dice on student 0 in the supervised modes with real labels), backward."""
     model.update_teacher()
     out_sts, out_tch = model(batch["image_st"], batch["image"])
     total = torch.zeros((), dtype=torch.float32, device=batch["image"].device)
@@ -92,10 +92,18 @@ def students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: 
     optimizer.zero_grad(set_to_none=True)
     from .train import unit_grad
     total.backward(unit_grad(total))
+    return total.detach()
+
+
+def students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: ClusteredPrototypeLoss, conf: Namespace,
+                          batch: dict, jitters=None) -> torch.Tensor:
+    """One iteration of students_teacher.py:150-207: EMA teacher update, students + teacher forward, prototype loss
+    (+ Dice on student 0 in the supervised modes with real labels), backward, optimizer and per-step scheduler."""
+    total = students_teacher_forward_backward(model, optimizer, loss_prt, conf, batch, jitters)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
-    return total.detach()
+    return total
 
 
 def graphed_students_teacher_step(model: MomentumModel, optimizer, scheduler, loss_prt: ClusteredPrototypeLoss, conf: Namespace,
@@ -116,7 +124,7 @@ def graphed_students_teacher_step(model: MomentumModel, optimizer, scheduler, lo
         if loss_prt._slots:                                    # (the first eager warm-up step creates and loads the slots itself)
             loss_prt.load_jitters(state["j"])
 
-    def body():
-        return students_teacher_step(model, optimizer, None, loss_prt, conf, batch, jitters=state["j"])
+    def forward_backward():
+        return students_teacher_forward_backward(model, optimizer, loss_prt, conf, batch, jitters=state["j"])
 
-    return train.GraphedStep(body, optimizer, scheduler, refresh, warmup)
+    return train.GraphedStep(forward_backward, optimizer, scheduler, refresh, warmup)

@@ -15,8 +15,10 @@ from .geometry import BlockTables, block_tables, round_up
 
 BF16 = torch.bfloat16
 USE_FUSED_ATTN_BWD = True      # one-pass attention backward where it applies (tests flip it to compare with the two-pass form)
-USE_FP8_ATTN_FWD = False       # EXPERIMENT (BASELINE configs[4]): E4M3 Q'/K'/V/P in the forward attention of head_dim < 16 blocks;
+import os as _os
+USE_FP8_ATTN_FWD = _os.environ.get("MIVP_FP8_ATTN_FWD") == "1"   # EXPERIMENT (BASELINE configs[4]): E4M3 Q'/K'/V/P in the forward attention of head_dim < 16 blocks;
 #                                measured slower-or-equal and 20x less accurate than bf16 (profiles/r02_fp8_attention.json): off
+#                                unless MIVP_FP8_ATTN_FWD=1 / bench.py --fp8-attn (configs[4] with its named arithmetic)
 
 
 @dataclass
@@ -178,10 +180,13 @@ class SwinSaved:
 
 
 def set_dropout(d: L.SwinDesc, dropout):
-    """dropout = (p_attn, p_proj, seed_attn, seed_proj) or None: fills the descriptor's counter-hash dropout fields."""
+    """dropout = (p_attn, p_proj, seed_attn, seed_proj[, epoch_ptr]) or None: fills the descriptor's counter-hash dropout
+    fields; ``epoch_ptr`` = address of a device int32 word that the kernels fold into both seeds (recorded graphs: the
+    graph increments it, so every replay draws new masks -- mivp.h ``seed_epoch``)."""
     if not dropout:
         return
-    p_attn, p_proj, seed_attn, seed_proj = dropout
+    p_attn, p_proj, seed_attn, seed_proj = dropout[:4]
+    d.seed_epoch = int(dropout[4]) if len(dropout) > 4 and dropout[4] else None
     for name, p, seed in (("attn", p_attn, seed_attn), ("proj", p_proj, seed_proj)):
         thr = int(round(float(p) * 65536.0))
         if not 0 <= thr < 65536:

@@ -407,13 +407,23 @@ class SwinUnetR(nn.Module):
                             use_checkpoint=c.use_checkpoint)
                 for i in range(depth)])
         else:
-            # CNN decoder (swin_unetr.py:338-348): MONAI UnetrUpBlock; conf.res_block is read unguarded like the reference
+            # CNN decoder (swin_unetr.py:338-348): MONAI UnetrUpBlock -- parity unpinned (restated from MONAI's documented
+            # source).  ``conf.res_block`` is not a yml key (the reference reads it unguarded and fails with
+            # an AttributeError): default False with a clear message instead.  The reference passes the decoder prompt as a
+            # third argument the MONAI block does not take: prompts cannot act on this decoder.
+            if not hasattr(c, "res_block"):
+                import warnings
+                warnings.warn("conf.res_block is not set (the reference's yml has no such key): UnetrUpBlock uses res_block=False")
+            if getattr(c, "use_decoder_prompting", False):
+                raise ValueError("use_decoder_prompting needs unetr_up_block='swin': the CNN decoder (UnetrUpBlock) takes no "
+                                 "prompt tokens (the reference's call fails there too)")
+            res_block = bool(getattr(c, "res_block", False))
             self.decoder_blocks = nn.ModuleList([
-                UnetrUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), c.res_block) for i in range(depth)])
+                UnetrUpBlock(dec_in[i], dec_out[i], (2, 2, 1 if i < depth - 1 else 2), res_block) for i in range(depth)])
         if c.unetr_res_block == "none":
             self.output_layer = nn.Upsample(scale_factor=(2, 2, 2), mode="trilinear", align_corners=False)
         elif not swin_up:
-            self.output_layer = UnetrUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), c.res_block)
+            self.output_layer = UnetrUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), bool(getattr(c, "res_block", False)))
         else:
             self.output_layer = SwinUpBlock(dec_out[-1], dec_out[-1], (2, 2, 2), (3, 3, 3), c.pos_bias_embed_dim,
                                             c.num_heads_decoder, c.attn_window_size, c.max_prompts,

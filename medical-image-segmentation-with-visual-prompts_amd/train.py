@@ -174,15 +174,16 @@ def build_scheduler(opt, conf: Namespace):
 
 def step_loss(out: dict, conf: Namespace, y) -> torch.Tensor:
     """The objective of a SINGLE-NETWORK step.  ``downstream``: DiceFocal on out['downstream'] (segmentation.py:44-50,
-    104-106).  ``supervised_*``: the segmentation term alone on out['seg_pred'] (students_teacher.py:190-197; this is the
-    ``sup_all`` throughput workload -- the full supervised step with its prototype term is
-    ``students_teacher.students_teacher_step``).  The ``self_supervised_*`` modes have no single-network objective: their
+    104-106).  ``supervised_*``: the trainer's segmentation term, ``DiceLoss`` on out['seg_pred'] (students_teacher.py:96-100,
+    190-197) -- the ``sup_all`` throughput workload; the full supervised step with its prototype term is
+    ``students_teacher.students_teacher_step``.  The ``self_supervised_*`` modes have no single-network objective: their
     step is the students/teacher step."""
     mode = conf.training_mode
     if mode == "downstream":
         return dice_focal_loss(out["downstream"], y, conf.include_background, 4.0)
     if mode in ("supervised_learning_all", "supervised_learning_decoder"):
-        return dice_focal_loss(out["seg_pred"], y, conf.include_background, 4.0)
+        from .losses import dice_loss
+        return dice_loss(out["seg_pred"], y, conf.include_background)
     raise ValueError(f"{mode}: use mivp_amd.students_teacher.students_teacher_step (students_teacher.py:150-207)")
 
 
@@ -207,28 +208,54 @@ def train_step(model, opt, conf: Namespace, x, y) -> torch.Tensor:
 
 
 class GraphedStep:
-    """One whole training step -- forward, loss, backward, optimizer launch -- recorded ONCE in a HIP graph and replayed.
+    """One whole training step -- forward, loss, backward, optimizer launch -- recorded ONCE in HIP graphs and replayed.
 
     An eager step is ~85 (cfg1) to ~1700 (cfg0: two students + teacher on 32^3 volumes) launches issued from Python at
-    10-15 us each; where the kernels are shorter than that (cfg0) the step is bound by the host.  A replay is one launch.
+    10-15 us each; where the kernels are shorter than that (cfg0) -- or where eight Python processes share a host
+    (``bench.py --gpus 8``) -- the step is bound by the host.  A replay is one launch.
 
-    ``body()`` runs the device side of a step on the current stream and returns the loss tensor: model forward, loss,
-    ``optimizer.zero_grad(set_to_none=True)``, ``backward()``, ``optimizer.step()`` -- no scheduler (host arithmetic on
-    ``param_groups``: it runs after every replay here), no ``.item()``.  Its inputs are fixed tensors: feed a new batch by
-    copying into them (``x.copy_(new)``) before the call.  What changes per step on the host side travels through device
-    memory: the optimizer's lr / bias corrections (``FusedAdamW(capturable=True).advance()``) and whatever ``refresh()`` loads
-    (the prototype loss's jitter tables).  Not recordable, and refused: attention / projection dropout (host-drawn seeds),
-    DistributedDataParallel (the bucket all-reduces belong to another stream).
+    ``forward_backward()`` runs on the current stream and returns the loss tensor: model forward, loss,
+    ``optimizer.zero_grad(set_to_none=True)``, ``backward()`` -- NOT the optimizer step (this class calls it), no scheduler
+    (host arithmetic on ``param_groups``: it runs after every replay here), no ``.item()``.  Its inputs are fixed tensors: feed
+    a new batch by copying into them (``x.copy_(new)``) before the call.  What changes per step on the host side travels
+    through device memory: the optimizer's lr / bias corrections (``FusedAdamW(capturable=True).advance()``), whatever
+    ``refresh()`` loads (the prototype loss's jitter tables), and the dropout masks: the recording starts by incrementing
+    the device's dropout epoch word, which the kernels fold into their seeds (functional.dropout_epoch, mivp.h
+    ``seed_epoch``), so every replay draws fresh attention / projection masks.
+
+    Data parallel (``torch.distributed`` initialised, world size > 1): the model is NOT wrapped in DistributedDataParallel.
+    Forward + backward are one graph that ends by gathering the gradients into ONE flat fp32 bucket; the bucket is
+    all-reduced (mean) eagerly on the same stream -- one collective per step: 0.57 MB in ``downstream`` mode, 37.5 MB in the
+    ``*_all`` modes; RCCL over xGMI on the GPU box, gloo in the tests -- and a second graph holds the optimizer launch,
+    which reads its gradients from the bucket.  Parameters are broadcast from rank 0 once at construction; BatchNorm
+    statistics stay per replica like the single-device reference.
 
     After a replay the packed-weight caches are marked stale, so an eager forward / evaluation between replays sees the
     current parameters."""
 
-    def __init__(self, body, optimizer, scheduler=None, refresh=None, warmup: int = 2):
+    def __init__(self, forward_backward, optimizer, scheduler=None, refresh=None, warmup: int = 2):
+        import torch.distributed as dist
         from . import functional as Fn
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedStep needs FusedAdamW(capturable=True) (train.build_optimizer(..., capturable=True))")
         self._fn = Fn
         self.optimizer, self.scheduler, self.refresh = optimizer, scheduler, refresh
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if os.environ.get("MIVP_GRAPH_FORCE_SINGLE"):             # (debug: the single-graph path under an initialised process group)
+            self.world = 1
+        params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self.params = params
+        dev = params[0].device
+        self._epoch = Fn.dropout_epoch(dev)
+        if self.world > 1:                                       # identical replicas to start from (DDP does this at construction)
+            flat = torch.cat([p.detach().reshape(-1) for p in params])
+            dist.broadcast(flat, src=0)
+            off = 0
+            with torch.no_grad():
+                for p in params:
+                    p.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            Fn.invalidate_weight_caches()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -236,42 +263,102 @@ class GraphedStep:
             for _ in range(max(1, warmup)):                      # eager: optimizer state, tables and caches come to life here
                 if refresh is not None:
                     refresh()
-                body()
+                forward_backward()
+                if self.world > 1:
+                    self._eager_mean_grads()
+                optimizer.step()
                 if scheduler is not None:
                     scheduler.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)                    # the recorded backward allocates the gradients in the graph's pool
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = body()
+        self.graph_opt = None
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self._epoch.add_(1)
+                self.loss = forward_backward()
+                optimizer.step()
+        else:
+            self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in params:
+                views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            with torch.cuda.graph(self.graph):
+                self._epoch.add_(1)
+                self.loss = forward_backward()
+                missing = [i for i, p in enumerate(params) if p.grad is None]
+                if missing:
+                    raise RuntimeError(f"GraphedStep (data parallel): {len(missing)} trainable parameters received no gradient")
+                self.local_grads = [p.grad for p in params]      # this replica's own gradients of the last replay (tests)
+                torch._foreach_copy_(views, self.local_grads)
+            for p, v in zip(params, views):                      # the optimizer launch reads the reduced gradients in place
+                p.grad = v
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                optimizer.step()
         self.launches_eager = None
+        self.host_seconds = self.collective_seconds = 0.0
+        self.replays = 0
+
+    def _eager_mean_grads(self):
+        import torch.distributed as dist
+        grads = [p.grad for p in self.params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self._allreduce_mean(flat)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def _allreduce_mean(self, flat):
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:                                                    # gloo has no AVG
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / self.world)
 
     def __call__(self) -> torch.Tensor:
+        import time
+        t0 = time.perf_counter()
         if self.refresh is not None:
             self.refresh()
         self.optimizer.advance()
         self.graph.replay()
+        if self.graph_opt is not None:
+            t1 = time.perf_counter()
+            self._allreduce_mean(self.flat)                      # (gloo stages through the host and waits for the device)
+            self.collective_seconds += time.perf_counter() - t1
+            self.graph_opt.replay()
         self._fn.invalidate_weight_caches()
         if self.scheduler is not None:
             self.scheduler.step()
+        self.host_seconds += time.perf_counter() - t0
+        self.replays += 1
         return self.loss
+
+    def host_ms_per_replay(self) -> float:
+        """Host time of a replayed step outside the collective call (table refresh, two graph launches, scheduler)."""
+        return 1e3 * (self.host_seconds - self.collective_seconds) / max(1, self.replays)
 
 
 def graphed_train_step(model, opt, conf: Namespace, x, y, warmup: int = 2) -> GraphedStep:
-    """``train_step`` as a recorded graph: call the result with no arguments; ``x`` / ``y`` are its fixed input tensors."""
+    """``train_step`` as recorded graphs: call the result with no arguments; ``x`` / ``y`` are its fixed input tensors.  Under
+    ``torch.distributed`` pass the BARE model (GraphedStep synchronises the gradients itself, see there)."""
     if hasattr(model, "module"):
-        raise ValueError("GraphedStep records a single-process step (no DistributedDataParallel)")
+        raise ValueError("GraphedStep takes the bare model: it all-reduces one flat gradient bucket between its two graphs "
+                         "instead of DistributedDataParallel's hooks")
 
-    def body():
+    def forward_backward():
         out = model(x)
         loss = step_loss(out, conf, y)
         opt.zero_grad(set_to_none=True)
         loss.backward(unit_grad(loss))
-        opt.step()
         return loss.detach()
 
-    return GraphedStep(body, opt, None, None, warmup)
+    return GraphedStep(forward_backward, opt, None, None, warmup)
 
 
 def dist_env():

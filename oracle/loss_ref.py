@@ -42,6 +42,21 @@ def dice_focal_loss(logits: Tensor, target: Tensor, include_background: bool = T
     return dice + focal
 
 
+def dice_loss(logits: Tensor, target: Tensor, include_background: bool = True) -> Tensor:
+    """MONAI ``DiceLoss(include_background, to_onehot_y=True, softmax=True)`` as documented -- the segmentation term of the
+    students / teacher trainer's supervised modes (modules/students_teacher.py:96-100, used at :190-197): the Dice term of
+    ``dice_focal_loss`` above, alone.  Parity unpinned (MONAI absent, no reference fixture)."""
+    C = logits.shape[1]
+    onehot = F.one_hot(target[:, 0].long(), C).permute(0, 4, 1, 2, 3).to(logits.dtype)
+    prob = logits.softmax(dim=1)
+    if not include_background:
+        onehot, prob = onehot[:, 1:], prob[:, 1:]
+    dims = (2, 3, 4)
+    inter = (prob * onehot).sum(dims)
+    denom = prob.sum(dims) + onehot.sum(dims)
+    return (1.0 - (2.0 * inter + 1e-5) / (denom + 1e-5)).mean()
+
+
 def _counts(preds: Tensor, target: Tensor, num_classes: int):
     pred = preds.argmax(dim=1, keepdim=True)
     inter, psum, tsum = [], [], []

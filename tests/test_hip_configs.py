@@ -26,7 +26,10 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-E2E_FP32 = 1.5e-2       # end-to-end logits (the reference's own bf16-autocast gap is 1.1-1.4e-2)
+# end-to-end logits, against the rounding-aware oracle (E2E_EMUL) and against the PLAIN fp32 oracle pinned to the reference's
+# fixtures (E2E_FP32): the same figure -- the reference's own bf16-autocast gap is 1.1-1.4e-2
+E2E_EMUL = 1.5e-2
+E2E_FP32 = 1.5e-2
 
 
 def r16(t):
@@ -80,7 +83,7 @@ def _check_stagewise(conf, sd, x, tag):
         assert restarted < bar, (tag, name, restarted, bar)
     # end to end the per-stage storage-rounding drift adds up (12 blocks x ~1e-3): the reference's own bf16 path is
     # 1.1-1.4e-2 away from its fp32 path
-    assert res["logits"][0] < E2E_FP32, res["logits"]
+    assert res["logits"][0] < E2E_EMUL, res["logits"]
     return res
 
 
@@ -97,6 +100,14 @@ def test_full_size_96_oracle_parity(workload):
     x = torch.rand(1, conf.input_channels, size, size, size, generator=gen)
     gout = torch.randn(1, conf.output_channels_downstream, size, size, size, generator=gen) / size ** 1.5
     _check_stagewise(conf, sd, x, f"{workload} 96^3")
+    # the same forward against the PLAIN fp32 oracle (no rounding emulation: the restatement that the reference's own
+    # fixtures pin), end to end
+    with torch.no_grad():
+        want32, _ = OracleSwinUnetR(conf, sd)(x, training=True)
+        got = _product(conf, sd, x)(x.to(DEV))["downstream"].float().cpu()
+    e32 = rel_l2(got, want32["downstream"])
+    print(f"[{workload} 96^3] logits rel-L2 vs the plain fp32 oracle {e32:.3e} (bar {E2E_FP32})")
+    assert e32 < E2E_FP32, e32
     if workload != "cfg2":
         return
     osd = {k: v.clone() for k, v in sd.items()}
@@ -158,7 +169,7 @@ def test_config3_reduced_size_oracle_parity():
     torch.cuda.synchronize()
     e16 = rel_l2(out.detach().cpu(), want["downstream"].detach())
     print(f"[cfg3 @64^3] logits rel-L2 vs rounding-aware oracle {e16:.3e}")
-    assert e16 < E2E_FP32, e16
+    assert e16 < E2E_EMUL, e16
     _check_stagewise(conf, sd, x, "cfg3 64^3")
     params = dict(model.named_parameters())
     assert sorted(k for k, q in params.items() if q.requires_grad) == sorted(keys)
@@ -177,12 +188,24 @@ def test_config3_reduced_size_oracle_parity():
             assert e < BWD_BAR.get(what, BWD_PARAM_BAR), (name, what, e)
 
 
-@pytest.mark.parametrize("workload,batch", [("cfg3", 2), ("cfg4", 8)])
-def test_config3_config4_full_size_properties(workload, batch):
+@pytest.fixture
+def fp8_attention(request):
+    from mivp_amd import swin_ops
+    old = swin_ops.USE_FP8_ATTN_FWD
+    swin_ops.USE_FP8_ATTN_FWD = bool(request.param)
+    yield bool(request.param)
+    swin_ops.USE_FP8_ATTN_FWD = old
+
+
+@pytest.mark.parametrize("workload,batch,fp8_attention", [("cfg3", 2, False), ("cfg4", 8, False), ("cfg4", 8, True)],
+                         indirect=["fp8_attention"])
+def test_config3_config4_full_size_properties(workload, batch, fp8_attention):
     """configs[3] at 4-ch 128^3 and configs[4]'s shape (96^3, batch 8, encoder prompts) through size-independent
     properties: eval-mode volumes are independent of their batch neighbours (flipping the batch flips the output bit for
     bit, sub-batches agree to rounding), and a training step produces a finite loss and finite gradients for exactly the
-    reference's downstream parameter partition."""
+    reference's downstream parameter partition.  configs[4] runs twice: in bf16 (the shipped default) and with its NAMED
+    arithmetic, the E4M3 MFMA window-attention forward (``swin_ops.USE_FP8_ATTN_FWD``; per-tensor scales, so a sub-batch is
+    quantised on another grid than the full batch: same bar, measured 2-3x the bf16 figure)."""
     from mivp_amd import train
     from mivp_amd.swin_unetr import SwinUnetR
     conf, size, _ = train.make_conf(workload)
@@ -247,13 +270,13 @@ def test_second_step_sees_the_first_steps_weights():
 
 
 def test_dice_difference_to_the_oracle_after_a_few_steps():
-    """North star: "Dice within 1e-4" -- measured here, asserted at 2e-4 for the reason given at the assertion.  At random init the two-class logits are near-tied everywhere (the reference's own
+    """North star: "Dice within 1e-4" -- asserted on the mean over sixteen unseen volumes (5e-4 per volume).  At random init the two-class logits are near-tied everywhere (the reference's own
     bf16 path agrees with its fp32 path on only 99.5-99.7 % of the voxels), so Dice is compared on a model a
     few optimisation steps in: a 96^3 volume with a bright blob whose mask the head learns, prompt
     tuning (configs[2]) for 80 steps on the HIP path, then HIP logits vs oracle logits on the trained state.  Dice =
     ``DiceCoefficient`` of the reference (utils.py:41-64, restated in oracle/loss_ref.py).  The oracle is the
-    fp32 restatement of the reference (no rounding emulation: the strict reading).  Evaluated on the training volume and five
-    unseen noise realisations; the bar applies to the mean (the validation metric), with a per-volume sanity bound."""
+    fp32 restatement of the reference (no rounding emulation: the strict reading).  Evaluated on the training volume and
+    sixteen unseen noise realisations; the bar applies to the mean (the validation metric), with a per-volume sanity bound."""
     from mivp_amd import train
     from mivp_amd.swin_unetr import SwinUnetR
     from oracle.unetr_ref import OracleSwinUnetR
@@ -278,7 +301,8 @@ def test_dice_difference_to_the_oracle_after_a_few_steps():
     model.eval()
     orc = OracleSwinUnetR(conf, round_weights(sd))
     diffs = []
-    for seed in (12, 101, 102, 103, 104, 105):                 # the training volume, then five unseen noise realisations
+    seeds = (12,) + tuple(range(101, 117))                     # the training volume, then sixteen unseen noise realisations
+    for seed in seeds:
         gen = torch.Generator().manual_seed(seed)
         img = (0.25 * torch.rand(size, size, size, generator=gen) + 0.2 + 0.5 * blob).clamp(0, 1)
         xe = img[None, None].to(DEV)
@@ -293,15 +317,14 @@ def test_dice_difference_to_the_oracle_after_a_few_steps():
               f"loss {losses[0]:.4f} -> {losses[-1]:.4f}  logits rel-L2 {rel_l2(got, want):.3e}")
         assert d_ref > 0.6                                     # the segmentation is non-trivial on both sides
         diffs.append(d_hip - d_ref)
-    # "Dice" is the validation metric: the mean over the evaluation volumes (the reference averages DiceCoefficient over
-    # its validation loader, downstream.py:147-165).  Per volume the two paths' bf16-vs-fp32 logit differences (~4.7e-3
-    # rel-L2 end to end) flip ~1e-4 of the voxels either way: single-volume differences scatter by about +-2e-4, and the
-    # six-volume mean moved between +1.8e-5 and +1.2e-4 from one build of this round to the next (every change of a
-    # kernel's summation order changes the 80-step trajectory, hence the trained state, hence which voxels sit on the
-    # fence).  The north star's 1e-4 is therefore AT the noise level of a bf16-storing path -- the reference's own bf16
-    # autocast differs from its fp32 path by 1.1-1.4e-2 in the logits, 2-3x what is measured here -- and the
-    # assertion is twice that: a real defect (a wrong tile, mask or scale) moves Dice by 1e-2 and more.
-    mean_diff = sum(diffs) / len(diffs)
-    print(f"[dice] mean signed difference over {len(diffs)} volumes {mean_diff:+.2e}; per volume {[f'{v:+.1e}' for v in diffs]}")
-    assert abs(mean_diff) <= 2e-4, diffs
+    # "Dice" is the validation metric: the mean over the evaluation volumes (the reference averages DiceCoefficient over its
+    # validation loader, segmentation.py:204-300).  Per volume the two paths' bf16-vs-fp32 logit differences (~4.7e-3 rel-L2
+    # end to end) flip ~1e-4 of the voxels either way: single-volume differences scatter by about +-2e-4 (round 2: the
+    # six-volume mean moved between +1.8e-5 and +1.2e-4 from build to build: trajectory noise).  Round 3 evaluates sixteen
+    # UNSEEN volumes and asserts the north star's own figure on their mean; the per-volume bound stays.
+    unseen = diffs[1:]
+    mean_diff = sum(unseen) / len(unseen)
+    print(f"[dice] mean signed difference over {len(unseen)} unseen volumes {mean_diff:+.2e} (training volume {diffs[0]:+.1e}); "
+          f"per volume {[f'{v:+.1e}' for v in unseen]}")
+    assert abs(mean_diff) <= 1e-4, diffs
     assert max(abs(v) for v in diffs) <= 5e-4, diffs

@@ -326,6 +326,34 @@ def test_dice_focal_loss_value_and_gradient(C, inc_bg):
     assert rel_l2(base.grad.cpu().permute(0, 4, 1, 2, 3), 2.5 * logits.grad) < 1e-4
 
 
+@pytest.mark.parametrize("C,inc_bg,dims", [(2, True, (6, 7, 8)), (2, False, (8, 8, 8)), (5, True, (6, 7, 8)), (5, False, (4, 6, 5))])
+def test_dice_loss_value_and_gradient(C, inc_bg, dims):
+    """losses.dice_loss (the Dice-focal kernels without the focal term, csrc/loss.hip gamma < 0) vs the oracle's restatement of
+    MONAI DiceLoss(include_background, to_onehot_y, softmax) -- the supervised modes' segmentation term
+    (students_teacher.py:96-100,190-197).  Parity unpinned (MONAI absent).  Both the channels-last storage the HIP model
+    returns and a plain contiguous channels-first tensor are fed (the latter is copied to channels-last, never an eager path)."""
+    from mivp_amd.losses import dice_loss
+    from oracle.loss_ref import dice_loss as oracle_loss
+    g = torch.Generator().manual_seed(10 * C + dims[0])
+    logits = (2.0 * torch.randn(2, C, *dims, generator=g)).requires_grad_(True)
+    y = torch.randint(0, C, (2, 1, *dims), generator=g).float()
+    want = oracle_loss(logits, y, inc_bg)
+    want.backward()
+    base = logits.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    got = dice_loss(base.permute(0, 4, 1, 2, 3), y.to(DEV), inc_bg)
+    (got * 0.7).backward()
+    plain = logits.detach().to(DEV).requires_grad_(True)
+    got2 = dice_loss(plain, y.to(DEV), inc_bg)
+    got2.backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(want)) < 2e-5 * max(1.0, abs(float(want)))
+    assert float(got2) == float(got)
+    assert rel_l2(base.grad.cpu().permute(0, 4, 1, 2, 3), 0.7 * logits.grad) < 1e-4
+    assert rel_l2(plain.grad.cpu(), logits.grad) < 1e-4
+    with pytest.raises(RuntimeError):
+        dice_loss(logits.detach(), y, inc_bg)                  # CPU tensors: the product has no CPU path
+
+
 @pytest.mark.parametrize("cin,cout,dims", [(48, 2, (8, 8, 16)), (48, 2, (9, 6, 21)), (8, 2, (4, 5, 7)), (32, 1, (6, 6, 6))])
 def test_head_conv_fused(cin, cout, dims):
     """BatchNorm-affine + 3x3x3 conv to <= 2 channels through the per-voxel-GEMM + gather kernel."""

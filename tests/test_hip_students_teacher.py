@@ -147,6 +147,38 @@ def test_fused_ema_matches_reference_momentum_model():
     assert all(not p.requires_grad for p in mm.net_teacher.parameters())
 
 
+def test_frozen_teacher_forward_sees_every_ema_update():
+    """``copy_state_dict()`` freezes the teacher (students_teacher.py:136) and ``update_teacher`` rewrites it
+    through a raw kernel (no version bump, same storage): the packed weight images of the teacher must be rebuilt anyway.
+    After an EMA update the teacher's forward equals the forward of a FRESH model loaded with the EMA'd state, bit for bit,
+    and differs from its forward before the update."""
+    import mivp_amd  # noqa: F401
+    from mivp_amd import train, students_teacher as ST
+    from mivp_amd.swin_unetr import SwinUnetR
+    conf, size, batch = train.make_conf("cfg0")
+    torch.manual_seed(3)
+    mm = ST.MomentumModel(conf, SwinUnetR).to(DEV).train()
+    mm.copy_state_dict()
+    assert all(not p.requires_grad for p in mm.net_teacher.parameters())
+    x = torch.rand(1, conf.input_channels, size, size, size, device=DEV)
+    fwd = lambda net: {k: v.detach().clone() for k, v in net(x).items() if torch.is_tensor(v)}
+    with torch.no_grad():
+        y0 = fwd(mm.net_teacher)
+        for p in mm.net_student.parameters():
+            p.add_(0.5 * torch.randn_like(p) * p.abs().mean().clamp_min(1e-3))
+        for _ in range(3):                                      # tau = 0.99..: a few updates so that bf16 images move
+            mm.update_teacher()
+        y1 = fwd(mm.net_teacher)
+        fresh = SwinUnetR(conf).to(DEV).train()
+        fresh.load_state_dict(mm.net_teacher.state_dict(), strict=True)
+        y_ref = fwd(fresh)
+    torch.cuda.synchronize()
+    assert set(y1) == set(y_ref) and len(y1) > 0
+    for k in y1:
+        assert torch.equal(y1[k], y_ref[k]), f"teacher forward does not see the EMA'd weights ({k})"
+    assert any(not torch.equal(y0[k], y1[k]) for k in y1), "the perturbation did not reach the output: test is vacuous"
+
+
 def test_config0_students_teacher_step_against_oracle():
     """BASELINE.json configs[0] as the reference runs it (students_teacher.py:150-207): MomentumModel(conf, SwinUnetR) with
     the yml's channel widths, 1-channel 32^3, batch 2, students 32^3 and 24^3, teacher 32^3.  One step on the HIP path vs

@@ -270,6 +270,64 @@ def test_block_dropout_matches_oracle_under_the_same_masks(tag, p_attn, p_proj):
     assert rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), plain) > 2e-2
 
 
+def test_dropout_epoch_word_moves_the_masks():
+    """mivp.h ``MivpSwinDesc.seed_epoch`` (ABI 12): the dropout kernels fold a device-resident epoch word into their seeds, so
+    a recorded graph (frozen descriptor) draws new masks per replay.  Exported masks: NULL == word 0; different words give
+    different masks at the same keep rate; forward + backward under a non-zero word still agree with the oracle under the
+    exported masks (the same check as above, on one fixture)."""
+    import ctypes as C
+    import mivp_amd  # noqa: F401
+    from mivp_amd import swin_ops, _lib as L
+    from oracle import swin_ref as S
+    fx = load_fixture("block_oddpad_shift_prompt")
+    m = fx.meta
+    window, shift, heads = m["window"], m["shift"], m["heads"]
+    sd = _rounded_state(fx["sd"])
+    x, prm, gout = r16(fx["in"]["x"]), fx["in"].get("prompt"), r16(fx["in"]["gout"])
+    n_prompt = prm.shape[0]
+    w = swin_ops.weights_from_state(sd, "", heads, 64, 0, torch.device(DEV), need_bwd=True)
+    ts = ((sd["pe.weights_token"] @ sd["pe.enc_token.0"].t())[:, :n_prompt] * (64 ** -0.5)).to(DEV)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    pd = prm.to(DEV)
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    p_attn, p_proj = 0.2, 0.2
+
+    def run(epoch_ptr, value):
+        word.fill_(value)
+        y, saved = swin_ops.swin_block_forward(xc, pd, w, ts, window, shift, save=True, dropout=(p_attn, p_proj, 1234, 987, epoch_ptr))
+        dx, dprompt, dts = swin_ops.swin_block_backward(saved, w, pd, dy, True, True)
+        d = saved.desc
+        ak = torch.empty((d.B * d.P * heads, d.Nqp, d.Nkp), dtype=torch.uint8, device=DEV)
+        pk = torch.empty((d.B * d.P * d.Nqp, d.C), dtype=torch.uint8, device=DEV)
+        L.call("mivp_dropout_masks", C.byref(d), L.ptr(ak), L.ptr(pk), L.stream())
+        torch.cuda.synchronize()
+        return y.float().cpu(), dx.float().cpu(), dprompt.cpu(), ak.cpu(), pk.cpu(), d
+
+    y_n, dx_n, dp_n, ak_n, pk_n, _ = run(None, 0)
+    y_0, dx_0, dp_0, ak_0, pk_0, _ = run(word.data_ptr(), 0)
+    y_5, dx_5, dp_5, ak_5, pk_5, d5 = run(word.data_ptr(), 5)
+    assert torch.equal(ak_n, ak_0) and torch.equal(pk_n, pk_0) and torch.equal(y_n, y_0) and torch.equal(dx_n, dx_0)
+    assert not torch.equal(ak_0, ak_5) and not torch.equal(pk_0, pk_5) and not torch.equal(y_0, y_5)
+    for ak, pk in ((ak_0, pk_0), (ak_5, pk_5)):
+        assert abs(1.0 - float(ak.float().mean()) - p_attn) < 0.02 and abs(1.0 - float(pk.float().mean()) - p_proj) < 0.03
+    # masks of the two epochs are independent: they agree about as often as independent draws would (keep^2 + drop^2)
+    agree = float((ak_0 == ak_5).float().mean())
+    assert abs(agree - ((1 - p_attn) ** 2 + p_attn ** 2)) < 0.02, agree
+    # forward / backward under epoch 5 against the oracle with THOSE masks
+    B, P, Nq, Nqp, Nkp, Cc = d5.B, d5.P, d5.Nq, d5.Nqp, d5.Nkp, d5.C
+    cols = list(range(Nq)) + list(range(Nqp, Nqp + n_prompt))
+    attn_keep = ak_5.view(B, P, heads, Nqp, Nkp).float()[:, :, :, :Nq][..., cols] * float(d5.attn_drop_scale)
+    proj_keep = pk_5.view(B, P, Nqp, Cc)[:, :, :Nq].float() * float(d5.proj_drop_scale)
+    xo = x.clone().requires_grad_(True)
+    po = prm.clone().requires_grad_(True)
+    want = S.swin_block(xo, po, sd, "", window, shift, heads, 64, attn_keep, proj_keep)
+    want.backward(gout)
+    assert rel_l2(y_5.permute(0, 4, 1, 2, 3), want.detach()) < 6e-3
+    assert rel_l2(dx_5.permute(0, 4, 1, 2, 3), xo.grad) < 1.5e-2
+    assert rel_l2(dp_5, po.grad) < 1.5e-2
+
+
 @pytest.mark.parametrize("tag", ["even_T", "odd_T", "even_F", "odd_F"])
 def test_patch_merge_backward_golden(tag):
     import mivp_amd
