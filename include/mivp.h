@@ -155,10 +155,18 @@ int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const float* t_w, 
 /* softmax((q k^T + bias) * mask) v per (window, head)  (window_attention.py:49-59)
  *   o [B*P][Nqp][C] bf16 (heads merged, channel = head*hd + j) ; lse [B*P][heads][Nqp] f32 (natural log; may be NULL
  *   when no backward pass will follow -- ABI 11)
- *   tok_rid [P][Nqp] int32: shift-mask region id of every window slot, 0 <= id < 254 (27 regions in 3D)        */
+ *   tok_rid [P][Nqp] int32: shift-mask region id of every window slot, 0 <= id < 254 (27 regions in 3D)
+ *   mask_words / cut_flags (ABI 12, shifted blocks only; both may be NULL: the kernel then compares tok_rid classes per
+ *   logit): the shift mask of swin_block.py:187-200,312-364 precomputed per window geometry as lane masks.
+ *   mask_words [P][Nqp/16 query tiles][Nqp/16 key tiles][4] uint64: bit 16 g + r of word j of (window pw, query tile qt, key
+ *   tile kt) is set when the logit of query slot 16 qt + r and key slot 16 kt + 4 g + j SURVIVES the multiplicative mask
+ *   (same region id; key rows >= Nq always survive -- they are excluded by their bias); query rows >= Nq carry class 0.
+ *   cut_flags [P] uint8: 1 when the window's content slots hold more than one region id (the others skip the mask).
+ *   The kernels load the words with scalar loads and apply each as ONE v_cndmask per logit.                         */
 int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v,
                       const void* kp, const void* vp, const void* qa, const void* ka,
-                      const int32_t* tok_rid, void* o, float* lse, mivp_stream_t stream);
+                      const int32_t* tok_rid, void* o, float* lse, const uint64_t* mask_words,
+                      const uint8_t* cut_flags, mivp_stream_t stream);
 
 /* proj + residual, drop prompts, LayerNorm + Linear + residual, scatter + crop
  * (window_attention.py:60, swin_block.py:221-253)

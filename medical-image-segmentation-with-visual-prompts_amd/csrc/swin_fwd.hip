@@ -413,19 +413,26 @@ MIVP_DEV bf16x4 attn_tr_read(const char* p) {
 
 // waves per SIMD asked of the register allocator: the one-k-step kernels hold four workgroups per CU (34 KB of LDS each at 7^3
 // windows) when they fit 64 VGPRs
-template <int DKS, bool DROP, bool MASKED, bool ZREF, bool DMA>
+template <int DKS, bool DROP, bool MASKED, bool ZREF, bool DMA, bool BITS>
 constexpr int attn_fwd_occupancy() {
     if (DKS != 1 || DROP) return 2;
-    if (DMA) return MASKED ? 6 : 8;          // (the masked steps need ~70 VGPRs: at 64 they spill around every tile)
+    // (the masked kernels need 68-72 VGPRs, with byte classes and with mask words: capped at 64 they spill around every tile)
+    if (DMA) return MASKED ? 6 : 8;
     return (MASKED && ZREF) ? 8 : 2;
 }
-template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED, bool ZREF = false, bool DMA = false>
-__global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZREF, DMA>())) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
+//   BITS (shifted blocks, mivp.h "mask words"): the shift mask of a (query tile, key tile) pair comes as four 64-bit lane
+//   masks from a per-geometry table (scalar loads -> v_cndmask on an SGPR pair: ONE vector instruction per logit) instead of
+//   byte classes compared per logit (extract + compare + select); cut windows cost ~2x an uncut one with the compares.
+template <int DKS, int DVT, int NW, int QT, bool DROP, bool ONES, bool MASKED, bool ZREF = false, bool DMA = false, bool BITS = false>
+__global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZREF, DMA, BITS>())) void k_win_attn_fwd(MivpSwinDesc d, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
                                                          const int* __restrict__ tok_rid, bf16_t* __restrict__ o,
-                                                         float* __restrict__ lse, int xcd_remap) {
+                                                         float* __restrict__ lse, int xcd_remap,
+                                                         const unsigned long long* __restrict__ mbits,
+                                                         const unsigned char* __restrict__ cutw) {
+    static_assert(!BITS || MASKED, "mask words belong to the masked kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DK = 32 * DKS;
     using KR = OperandRows<DK>;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
     }
     }
     // ---- key classes (classify_logit in common.hpp) ----
-    if (MASKED) {                                            // (only the masked steps read the classes)
+    if (MASKED && !BITS) {                                   // (only the masked steps of the class-compare form read them)
         for (int m = tid; m < Nkp; m += 64 * NW) {
             // content key: region id; prompt and padding keys: 254 = never masked (padding keys are excluded by their bias)
             ridk[m] = (uint8_t)(m < d.Nq ? tok_rid[pw * Nqp + m] : 254);
@@ -581,7 +588,9 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
     // Most windows of a shifted block are not cut by the volume boundary: all their content tokens share one region id
     // and the mask is a no-op.  Those windows take the unmasked steps (workgroup-uniform choice).
     bool cut = false;
-    if (MASKED) {
+    if (MASKED && BITS) {
+        cut = cutw[pw] != 0;                                 // per-window flag of the mask table (uniform: a scalar load)
+    } else if (MASKED) {
         int differs = 0;
         for (int m = tid; m < d.Nq; m += 64 * NW) differs |= ridk[m] != ridk[0];
         cut = __syncthreads_or(differs) != 0;
@@ -589,6 +598,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
 
     const int npairs = Nkp / 32;                             // key tiles come in pairs (Nkp % 32 == 0)
     const int nt_full = d.Nq / 16;                           // tiles made of valid content keys only
+    const int nkt_c = Nqp / 16;                              // key tiles that hold content rows (the mask table covers these)
     constexpr float RESCALE_LOG2 = 8.f;
 
     // A wave carries QT query tiles through the key loop at once: every K' / V^T fragment read from LDS serves QT tiles
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
             for (int a = 0; a < QT; ++a) {
                 const int ao = (qt_first + a < nqt) ? a : 0;  // an odd tile count: the spare slot shadows the first tile
                 const int row = (qt_first + ao) * 16 + r;
-                rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, (int)ridk[min(row, d.Nq - 1)], 0) : 0u;   // (the key classes hold the same ids)
+                rqo[a] = (MASKED && !BITS) ? (uint32_t)sel(row < d.Nq, (int)ridk[min(row, d.Nq - 1)], 0) : 0u;   // (the key classes hold the same ids)
 #pragma unroll
                 for (int s = 0; s < DKS; ++s)
                     qfo[a][s] = cat44(*reinterpret_cast<const bf16x4*>(qsrc[s][0] + ao * q_tile[s][0]),
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
             for (int a = 0; a < QT; ++a) {
                 const int qt = (qt_first + a < nqt) ? qt_first + a : (qt_first < nqt ? qt_first : 0);
                 const int row = qt * 16 + r;
-                rqo[a] = MASKED ? (uint32_t)sel(row < d.Nq, tok_rid[pw * Nqp + min(row, d.Nq - 1)], 0) : 0u;
+                rqo[a] = (MASKED && !BITS) ? (uint32_t)sel(row < d.Nq, tok_rid[pw * Nqp + min(row, d.Nq - 1)], 0) : 0u;
 #pragma unroll
                 for (int s = 0; s < DKS; ++s) {
                     bf16x4 piece[2];
@@ -665,6 +675,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
     if (!DMA || QT * wave < nqt) load_q(QT * wave, qf_next, rq_next);
     for (int qt0 = QT * wave; qt0 < nqt; qt0 += QT * NW) {
         int qrow[QT];
+        const unsigned long long* mrow[QT];                  // (BITS) mask words of this query tile: [key tile][4]
         uint32_t rq[QT];
         bf16x8 qf[QT][DKS];
         f32x4 oacc[QT][DVT], negm[QT];                       // negm = -(reference point): the accumulator the S MFMA starts from
@@ -674,6 +685,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
         for (int a = 0; a < QT; ++a) {
             const int qt = (qt0 + a < nqt) ? qt0 + a : qt0;  // an odd tile count: the spare slot shadows tile qt0, nothing stored
             qrow[a] = qt * 16 + r;
+            if (BITS) mrow[a] = mbits + ((long)pw * nqt + qt) * (long)(4 * nkt_c);
             rq[a] = rq_next[a];
 #pragma unroll
             for (int s = 0; s < DKS; ++s) qf[a][s] = qf_next[a][s];
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                 for (int s = 0; s < DKS; ++s)
                     kfr[hh][s] = *reinterpret_cast<const bf16x8*>(Kimg + KR::off(16 * (2 * u + hh) + r, 32 * s + 8 * g));
             uint32_t kcl[2] = {0u, 0u};
-            if (MASK) {
+            if (MASK && !BITS) {
                 kcl[0] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u) + 4 * g);
                 kcl[1] = *reinterpret_cast<const uint32_t*>(ridk + 16 * (2 * u + 1) + 4 * g);
             }
@@ -735,7 +747,17 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                     f32x4 acc = ZSEED ? fzero4() : negm[a];
 #pragma unroll
                     for (int s = 0; s < DKS; ++s) acc = mfma16(kfr[hh][s], qf[a][s], acc);
-                    if (MASK) {
+                    if (MASK && BITS) {
+                        // four lane masks of this (query tile, key tile): bit 16 g + r = "logit (query r, key 4 g + j) survives";
+                        // tiles beyond the content rows (prompt keys) are never masked and have no words
+                        if (!TAIL || t < nkt_c) {
+                            const unsigned long long* mw = mrow[a] + 4 * t;
+                            acc[0] = __builtin_amdgcn_inverse_ballot_w64(mw[0]) ? acc[0] : masked_logit;
+                            acc[1] = __builtin_amdgcn_inverse_ballot_w64(mw[1]) ? acc[1] : masked_logit;
+                            acc[2] = __builtin_amdgcn_inverse_ballot_w64(mw[2]) ? acc[2] : masked_logit;
+                            acc[3] = __builtin_amdgcn_inverse_ballot_w64(mw[3]) ? acc[3] : masked_logit;
+                        }
+                    } else if (MASK) {
                         const uint32_t kr = kcl[hh];
                         if (!TAIL || t < nt_full) {
                             acc[0] = ((kr & 0xFFu) == rq[a]) ? acc[0] : masked_logit;
@@ -1145,22 +1167,23 @@ extern "C" int mivp_relbias_aug(const MivpSwinDesc* d, const float* t_h, const f
     return mivp_check_launch("relbias_aug");
 }
 
-template <int DKS, int DVT, int NW, int QT, bool DMA>
+template <int DKS, int DVT, int NW, int QT, bool DMA, bool BITS>
 static int launch_attn_fwd_cfg(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                                const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
-                               hipStream_t st) {
+                               const unsigned long long* mask_words, const unsigned char* cut_flags, hipStream_t st) {
     const size_t krow = OperandRows<32 * DKS>::ROW, vrow = (d->Nkp + 8) * 2;
     const size_t lds = (size_t)d->Nkp * krow + (DMA ? (size_t)d->Nkp * 32 : (size_t)16 * DVT * vrow) + (size_t)d->Nkp;
     if (lds > 160 * 1024) { mivp_set_error("win_attn_fwd: LDS image exceeds 160 KiB"); return MIVP_EUNSUPPORTED; }
     const bool ones = !d->attn_drop_thr && (d->C / d->heads) < 16 * DVT;
     const bool msk = d->has_mask != 0;
     const bool zref = lse == nullptr && !d->attn_drop_thr;      // forward only (kernel header: ZREF)
+    // (BITS only ever instantiates masked kernels: the un-masked arms below pass false)
     auto kern = d->attn_drop_thr
-        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, true, false, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, true, false, false, false, DMA>)
-        : ones ? (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, true, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, true, DMA>)
-                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, false, DMA>))
-               : (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, true, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, true, DMA>)
-                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, false, DMA> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, false, DMA>));
+        ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, true, false, true, false, DMA, BITS> : k_win_attn_fwd<DKS, DVT, NW, QT, true, false, false, false, DMA, false>)
+        : ones ? (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, true, DMA, BITS> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, true, DMA, false>)
+                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, true, true, false, DMA, BITS> : k_win_attn_fwd<DKS, DVT, NW, QT, false, true, false, false, DMA, false>))
+               : (zref ? (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, true, DMA, BITS> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, true, DMA, false>)
+                       : (msk ? k_win_attn_fwd<DKS, DVT, NW, QT, false, false, true, false, DMA, BITS> : k_win_attn_fwd<DKS, DVT, NW, QT, false, false, false, false, DMA, false>));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mivp_set_error(hipGetErrorString(e)); return MIVP_ELAUNCH; }
@@ -1169,27 +1192,31 @@ static int launch_attn_fwd_cfg(const MivpSwinDesc* d, const void* q, const void*
     static const bool no_remap = getenv("MIVP_ATTN_NO_XCD_REMAP") != nullptr;
     const int xcd_remap = (!no_remap && grid % 8 == 0 && grid >= 64) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, *d, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse, xcd_remap);
+                       (const bf16_t*)kp, (const bf16_t*)vp, (const bf16_t*)qa, (const bf16_t*)ka, tok_rid, (bf16_t*)o, lse, xcd_remap,
+                       mask_words, cut_flags);
     return mivp_check_launch("win_attn_fwd");
 }
 
 template <int DKS, int DVT>
 static int launch_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                            const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o, float* lse,
-                           hipStream_t st) {
+                           const unsigned long long* mw, const unsigned char* cf, hipStream_t st) {
     // (NW, QT) = (4, 2) -- two query tiles per wave sharing every K' / V^T fragment -- measures the same as (8, 1) at 7^3
     // windows (87.5 vs 87.2 us per stage-1 block): the kernel is bound by VALU issue, not by the LDS pipe
+    static const bool no_bits = getenv("MIVP_ATTN_MASK_CLASSES") != nullptr;       // A/B: byte classes instead of mask words
+    const bool bits = d->has_mask && mw != nullptr && cf != nullptr && !no_bits;
     // one k-step / one value tile (head_dim <= 16: the encoder stages and the last decoder stage): LDS-DMA staged images
     // (MIVP_ATTN_FWD_REG_STAGING=1 keeps the register-path staging for A/B runs)
     if constexpr (DKS == 1 && DVT == 1) {
         static const bool reg_staging = getenv("MIVP_ATTN_FWD_REG_STAGING") != nullptr;
-        // (the masked kernels need ~72 VGPRs in this form: three workgroups per CU; round 2's classic masked forward-only
-        //  kernel squeezed into 64 without scratch and measured 148 us per stage-0 launch against 153 here, the unmasked
-        //  ones gain 5 %)
-        if (!reg_staging && d->Nqp % 8 == 0)
-            return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+        // (the masked kernels need ~72 VGPRs in this form with byte classes: three workgroups per CU)
+        if (!reg_staging && d->Nqp % 8 == 0) {
+            if (bits) return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cf, st);
+            return launch_attn_fwd_cfg<DKS, DVT, 8, 1, true, false>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cf, st);
+        }
     }
-    return launch_attn_fwd_cfg<DKS, DVT, 8, 1, false>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    if (bits) return launch_attn_fwd_cfg<DKS, DVT, 8, 1, false, true>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cf, st);
+    return launch_attn_fwd_cfg<DKS, DVT, 8, 1, false, false>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cf, st);
 }
 
 // shared by forward and backward dispatch: which (NT, DKS=DVT) instantiation covers this shape
@@ -1207,7 +1234,7 @@ int mivp_attn_tile_config(const MivpSwinDesc* d, int* dks, int* nt) {
 
 extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const void* k, const void* v, const void* kp,
                                  const void* vp, const void* qa, const void* ka, const int32_t* tok_rid, void* o,
-                                 float* lse, mivp_stream_t stream) {
+                                 float* lse, const uint64_t* mask_words, const uint8_t* cut_flags, mivp_stream_t stream) {
     int rc = swin_common_checks(d);
     if (rc) return rc;
     MIVP_REQUIRE(q && k && v && qa && ka && o);             // lse may be NULL (ABI 11): forward only, nothing saved
@@ -1216,9 +1243,10 @@ extern "C" int mivp_win_attn_fwd(const MivpSwinDesc* d, const void* q, const voi
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_fwd: head_dim / key count outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (dks == 1) return launch_attn_fwd<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
-    if (dks == 2) return launch_attn_fwd<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
-    return launch_attn_fwd<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, st);
+    const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(mask_words);
+    if (dks == 1) return launch_attn_fwd<1, 1>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cut_flags, st);
+    if (dks == 2) return launch_attn_fwd<2, 2>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cut_flags, st);
+    return launch_attn_fwd<3, 3>(d, q, k, v, kp, vp, qa, ka, tok_rid, o, lse, mw, cut_flags, st);
 }
 
 extern "C" int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, const void* x, const int32_t* tok_src,

@@ -9,7 +9,7 @@ coordinates.  Built with numpy, cached per (dims, window, shift_cfg, device).
 """
 from dataclasses import dataclass
 from functools import lru_cache
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -33,6 +33,8 @@ class BlockTables:
     tok_src: torch.Tensor                 # int32 [P*Nqp] on device
     tok_dst: torch.Tensor
     tok_rid: torch.Tensor
+    mask_words: Optional[torch.Tensor] = None     # shifted blocks: int64 [P][Nqp/16][Nqp/16][4] lane masks (mivp.h), forward layout
+    cut_flags: Optional[torch.Tensor] = None      # uint8 [P]
 
 
 def _axis_tables(dim, w, s, t):
@@ -94,9 +96,42 @@ def build_tables_numpy(dims, window, shift_cfg):
     return meta, out
 
 
+def mask_words_numpy(rid: np.ndarray, P: int, Nq: int, Nqp: int):
+    """The shift mask as lane masks (mivp.h ``mask_words``): ``rid`` int32 [P * Nqp] region ids (swin_block.py:312-364 through
+    build_tables_numpy).  Returns (forward words, backward words, cut flags).  Logit (query n, key m) of a window survives the
+    multiplicative mask (swin_block.py:187-200) when both slots carry the same region id; key rows >= Nq (content padding)
+    always survive, query rows >= Nq compare as class 0 -- exactly the classes the byte-compare kernels use.
+      forward  word j of (qt, kt): bit 16 g + r <-> (query 16 qt + r, key 16 kt + 4 g + j)        (query on the lane)
+      backward word j of (qt, kt): bit 16 g + r <-> (query 16 qt + 4 g + j, key 16 kt + r)        (key on the lane)"""
+    rid = rid.reshape(P, Nqp)
+    slot = np.arange(Nqp)
+    qcls = np.where(slot[None, :] < Nq, rid, 0)
+    kcls = np.where(slot[None, :] < Nq, rid, 254)
+    nt = Nqp // 16
+    fwd = np.empty((P, nt, nt, 4), np.uint64)
+    bwd = np.empty((P, nt, nt, 4), np.uint64)
+    cut = np.zeros(P, np.uint8)
+    for p in range(P):                                            # (one window at a time: 352 x 352 booleans)
+        live = (kcls[p][None, :] == 254) | (kcls[p][None, :] == qcls[p][:, None])          # [query, key]
+        cut[p] = np.unique(rid[p, :Nq]).size > 1
+        a = live.reshape(nt, 16, nt, 4, 4)                        # [qt, r, kt, g, j]
+        bits = np.ascontiguousarray(a.transpose(0, 2, 4, 3, 1)).reshape(nt, nt, 4, 64)      # [qt, kt, j, (g, r)]
+        fwd[p] = np.packbits(bits, axis=-1, bitorder="little").view(np.uint64).reshape(nt, nt, 4)
+        b = live.reshape(nt, 4, 4, nt, 16)                        # [qt, g, j, kt, r]
+        bits = np.ascontiguousarray(b.transpose(0, 3, 2, 1, 4)).reshape(nt, nt, 4, 64)      # [qt, kt, j, (g, r)]
+        bwd[p] = np.packbits(bits, axis=-1, bitorder="little").view(np.uint64).reshape(nt, nt, 4)
+    return fwd, bwd, cut
+
+
 @lru_cache(maxsize=256)
 def block_tables(dims, window, shift_cfg, device_str) -> BlockTables:
     meta, (src, dst, rid) = build_tables_numpy(dims, window, shift_cfg)
     dev = torch.device(device_str)
+    extra = {}
+    if meta["has_mask"]:
+        fwd, bwd, cut = mask_words_numpy(rid, meta["P"], meta["Nq"], meta["Nqp"])
+        # (the backward layout was built and measured too: in the fused backward the scalar loads share the LDS wait counter with
+        #  the tile loop's dS exchange and the launch got 7 % SLOWER -- 419 vs 391 us at stage 0 -- so only the forward uses words)
+        extra = dict(mask_words=torch.from_numpy(fwd.view(np.int64)).to(dev), cut_flags=torch.from_numpy(cut).to(dev))
     return BlockTables(tok_src=torch.from_numpy(src).to(dev), tok_dst=torch.from_numpy(dst).to(dev),
-                       tok_rid=torch.from_numpy(rid).to(dev), **meta)
+                       tok_rid=torch.from_numpy(rid).to(dev), **meta, **extra)

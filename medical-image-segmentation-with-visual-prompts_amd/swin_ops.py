@@ -250,8 +250,12 @@ def swin_block_forward(x: torch.Tensor, prompt: Optional[torch.Tensor], w: SwinB
     fp8 = USE_FP8_ATTN_FWD and hd < 16 and hd + d.augp <= 32 and not dropout
     # the log-sum-exp rows feed the backward passes only (the fp8 experiment's kernel always writes them)
     lse = torch.empty((BP, w.heads, d.Nqp), dtype=torch.float32, device=dev) if (save or fp8) else None
-    L.call("mivp_win_attn_fwd_fp8" if fp8 else "mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp),
-           L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
+    if fp8:
+        L.call("mivp_win_attn_fwd_fp8", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp),
+               L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), st)
+    else:
+        L.call("mivp_win_attn_fwd", C.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(kp), L.ptr(vp),
+               L.ptr(qa), L.ptr(ka), L.ptr(tb.tok_rid), L.ptr(o), L.ptr(lse), L.ptr(tb.mask_words), L.ptr(tb.cut_flags), st)
     t1 = torch.empty((BP, d.Nqp, Cc), dtype=BF16, device=dev) if save else None
     y = torch.empty_like(x)
     L.call("mivp_swin_proj_mlp_fwd", C.byref(d), L.ptr(o), L.ptr(x), L.ptr(tb.tok_src), L.ptr(tb.tok_dst), L.ptr(w.wproj_f),

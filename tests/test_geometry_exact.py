@@ -34,6 +34,39 @@ def test_region_ids_reproduce_reference_masks_bit_exactly(tag):
     assert meta["has_mask"] == any(s > 0 for s in meta["shift"])
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_mask_words_reproduce_reference_masks_bit_exactly(tag):
+    """The lane-mask form of the shift mask (geometry.mask_words_numpy, mivp.h ``mask_words``: what the attention forward reads
+    through scalar loads) against the reference's own ``get_attn_mask`` outputs: every bit of every word for the content
+    slots, "always survives" for the padding key rows, the per-window cut flag."""
+    from mivp_amd.geometry import mask_words_numpy
+    fx = load_fixture(f"mask_{tag}")
+    m = fx.meta
+    meta, (_, _, rid) = build_tables_numpy(m["dims"], m["window"], m["shift"])
+    if not meta["has_mask"]:
+        return
+    P, Nq, Nqp = meta["P"], meta["Nq"], meta["Nqp"]
+    fwd, bwd, cut = mask_words_numpy(rid, P, Nq, Nqp)
+    want = fx["out"]["mask"].numpy() != 0                          # [P, Nq, Nq]: 1 where the logit survives
+    nt = Nqp // 16
+    assert fwd.shape == bwd.shape == (P, nt, nt, 4) and fwd.dtype == np.uint64
+    lane = np.arange(64, dtype=np.uint64)
+    g, r = (lane >> np.uint64(4)).astype(np.int64), (lane & np.uint64(15)).astype(np.int64)
+    live_f = np.zeros((P, Nqp, Nqp), bool)
+    live_b = np.zeros((P, Nqp, Nqp), bool)
+    for qt in range(nt):
+        for kt in range(nt):
+            for j in range(4):
+                bits_f = ((fwd[:, qt, kt, j][:, None] >> lane[None, :]) & np.uint64(1)).astype(bool)      # [P, 64]
+                live_f[:, 16 * qt + r, 16 * kt + 4 * g + j] = bits_f
+                bits_b = ((bwd[:, qt, kt, j][:, None] >> lane[None, :]) & np.uint64(1)).astype(bool)
+                live_b[:, 16 * qt + 4 * g + j, 16 * kt + r] = bits_b
+    assert np.array_equal(live_f[:, :Nq, :Nq], want)
+    assert np.array_equal(live_b, live_f)                          # the two layouts hold the same matrix
+    assert live_f[:, :, Nq:].all()                                 # padding key rows always survive (their bias excludes them)
+    assert np.array_equal(cut != 0, np.array([np.unique(x).size > 1 for x in rid.reshape(P, Nqp)[:, :Nq]]))
+
+
 def _oracle_maps(dims, window, shift_cfg):
     """(src, dst) voxel index per (window, slot) from the oracle's geometry: the padded frame holds the volume at
     [hi, hi + dim) (pad: ceil in front) and the output is cropped from [lo, L - hi) (floor in front)."""
