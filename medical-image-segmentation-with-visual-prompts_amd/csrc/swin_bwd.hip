@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 3 : 4)) void k_swin_
                                                            bf16_t* __restrict__ d_o, bf16_t* __restrict__ d_t1,
                                                            bf16_t* __restrict__ dn_out, bf16_t* __restrict__ dyw,
                                                            bf16_t* __restrict__ d_pj) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     // dn_out / dyw (optional, weight-gradient mode): gradient w.r.t. the mlp_norm output and dy in window order;
     // d_pj (optional): dt1 under the proj-dropout mask = gradient w.r.t. the proj output
     constexpr int KS = (CT + 1) / 2;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 3 : 4)) void k_swin_
                 if (ti.live) st4(d_t1 + ti.tt * (long)C + n0, out);      // the residual branch sees dt1 unmasked
                 if (d.proj_drop_thr) {
                     const uint32_t pi = (uint32_t)((ti.tt * C + n0) >> 1);
-                    const uint32_t h0 = drop_hash(pi, drop_seed(d.proj_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.proj_seed, d.seed_epoch));
+                    const uint32_t h0 = drop_hash(pi, proj_key), h1 = drop_hash(pi + 1, proj_key);
                     v[0] = drop_keep(h0, 0, d.proj_drop_thr) ? v[0] * d.proj_drop_scale : 0.f;
                     v[1] = drop_keep(h0, 1, d.proj_drop_thr) ? v[1] * d.proj_drop_scale : 0.f;
                     v[2] = drop_keep(h1, 0, d.proj_drop_thr) ? v[2] * d.proj_drop_scale : 0.f;
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
                                                          const int* __restrict__ tok_rid, const bf16_t* __restrict__ o,
                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                          float* __restrict__ delta, bf16_t* __restrict__ dq) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = AttnBwdGeom<DKS, DVT>;
     constexpr int DK = G::DK, DVS = G::DVS, DVP = G::DVP, KROW = G::KROW, VROWB = G::VROWB;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_at
                     }
                     if (DROP) {                              // dP = dropout'(dO V^T): same mask and scale as the forward
                         const uint32_t pi = attn_pair(drow, 16 * (t0 + lt) + 4 * g);
-                        const uint32_t h0 = drop_hash(pi, drop_seed(d.attn_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.attn_seed, d.seed_epoch));
+                        const uint32_t h0 = drop_hash(pi, attn_key), h1 = drop_hash(pi + 1, attn_key);
                         dp[0] = drop_keep(h0, 0, d.attn_drop_thr) ? dp[0] * d.attn_drop_scale : 0.f;
                         dp[1] = drop_keep(h0, 1, d.attn_drop_thr) ? dp[1] * d.attn_drop_scale : 0.f;
                         dp[2] = drop_keep(h1, 0, d.attn_drop_thr) ? dp[2] * d.attn_drop_scale : 0.f;
@@ -506,6 +512,9 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                                                           bf16_t* __restrict__ dv, float* __restrict__ dkp_part,
                                                           float* __restrict__ dvp_part, float* __restrict__ dtok_part,
                                                           float* __restrict__ dka_part) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     // AUG (weight-gradient mode): also accumulates dK' over the 32 bias-augmentation columns, i.e.
     // dka_part[bph][key][a] = sum_n dS[n, key] * qa[n][a]  (f32 [B*P*heads][Nkp][32]): the window-local gradient of
     // the relative-position-bias table values that mivp_relbias_aug laid out on the key side.
@@ -726,7 +735,7 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                         for (int j = 0; j < 4; ++j) {
                             float keep = 1.f;
                             if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
-                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
+                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), attn_key);
                                 keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                             }
                             float p, dsv;
@@ -1242,6 +1251,9 @@ extern "C" int mivp_prompt_kv_bwd(const MivpSwinDesc* d, const float* dkp, const
 
 // test hook: materialise the keep masks exactly as the kernels derive them
 __global__ __launch_bounds__(256) void k_dropout_masks(MivpSwinDesc d, uint8_t* __restrict__ attn_keep, uint8_t* __restrict__ proj_keep) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
     if (attn_keep) {
         const long total = (long)d.B * d.P * d.heads * d.Nqp * d.Nkp;
@@ -1250,14 +1262,14 @@ __global__ __launch_bounds__(256) void k_dropout_masks(MivpSwinDesc d, uint8_t* 
             const long rest = e / d.Nkp;
             const int q = (int)(rest % d.Nqp);
             const long bph = rest / d.Nqp;
-            const uint32_t h = drop_hash(attn_pair(attn_row(bph, q, d.Nqp, d.Nkp), k), drop_seed(d.attn_seed, d.seed_epoch));
+            const uint32_t h = drop_hash(attn_pair(attn_row(bph, q, d.Nqp, d.Nkp), k), attn_key);
             attn_keep[e] = (d.attn_drop_thr == 0 || drop_keep(h, k & 1, d.attn_drop_thr)) ? 1 : 0;
         }
     }
     if (proj_keep) {
         const long total = (long)d.B * d.P * d.Nqp * d.C;
         for (long e = gtid; e < total; e += stride) {
-            const uint32_t h = drop_hash((uint32_t)(e >> 1), drop_seed(d.proj_seed, d.seed_epoch));
+            const uint32_t h = drop_hash((uint32_t)(e >> 1), proj_key);
             proj_keep[e] = (d.proj_drop_thr == 0 || drop_keep(h, (int)(e & 1), d.proj_drop_thr)) ? 1 : 0;
         }
     }

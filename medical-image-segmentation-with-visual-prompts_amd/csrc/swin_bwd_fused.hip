@@ -162,6 +162,9 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
     const bf16_t* __restrict__ ka, const int* __restrict__ tok_rid, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ d_o, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
     bf16_t* __restrict__ dv, float* __restrict__ dkp_part, float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a SCALAR: everything derived from it (key-tile ownership, LDS slots) stays in SGPRs and the
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                     float keep = 1.f;
                     if (DROP) {                                // element (query 16t + 4g + j, key 16 kt + r)
                         const int krow = 16 * (wave + NW * i) + r;
-                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
+                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), attn_key);
                         keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                     }
                     const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
@@ -511,6 +514,9 @@ __global__ __launch_bounds__(64 * NW, DROP ? 4 : 8) void k_win_attn_bwd_prompt(
     MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
     const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
     const float* __restrict__ lse, float* __restrict__ dkp_part, float* __restrict__ dvp_part, float* __restrict__ dtok_part) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, DROP ? 4 : 8) void k_win_attn_bwd_prompt(
             float keep = 1.f;
             if (DROP) {
                 const int krow = Nqp + trow;
-                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), drop_seed(d.attn_seed, d.seed_epoch));
+                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), attn_key);
                 keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
             }
             const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];

@@ -415,7 +415,8 @@ MIVP_DEV bf16x4 attn_tr_read(const char* p) {
 // windows) when they fit 64 VGPRs
 template <int DKS, bool DROP, bool MASKED, bool ZREF, bool DMA, bool BITS>
 constexpr int attn_fwd_occupancy() {
-    if (DKS != 1 || DROP) return 2;
+    if (DKS != 1) return 2;
+    if (DROP) return DMA ? 6 : 2;            // (dropout kernels: ~90-115 VGPRs left alone = two workgroups per CU; 80 = three)
     // (the masked kernels need 68-72 VGPRs, with byte classes and with mask words: capped at 64 they spill around every tile)
     if (DMA) return MASKED ? 6 : 8;
     return (MASKED && ZREF) ? 8 : 2;
@@ -432,6 +433,9 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                                                          float* __restrict__ lse, int xcd_remap,
                                                          const unsigned long long* __restrict__ mbits,
                                                          const unsigned char* __restrict__ cutw) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     static_assert(!BITS || MASKED, "mask words belong to the masked kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DK = 32 * DKS;
@@ -829,14 +833,31 @@ __global__ __launch_bounds__(64 * NW, (attn_fwd_occupancy<DKS, DROP, MASKED, ZRE
                     for (int hh = 0; hh < 2; ++hh) {
                         const int key0 = 16 * (2 * u + hh) + 4 * g;
                         const uint32_t pi = attn_pair(drow[a], key0);
-                        const uint32_t h0 = drop_hash(pi, drop_seed(d.attn_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.attn_seed, d.seed_epoch));
+                        const uint32_t h0 = drop_hash(pi, attn_key), h1 = drop_hash(pi + 1, attn_key);
                         sv[a][hh][0] = drop_keep(h0, 0, d.attn_drop_thr) ? sv[a][hh][0] : 0.f;
                         sv[a][hh][1] = drop_keep(h0, 1, d.attn_drop_thr) ? sv[a][hh][1] : 0.f;
                         sv[a][hh][2] = drop_keep(h1, 0, d.attn_drop_thr) ? sv[a][hh][2] : 0.f;
                         sv[a][hh][3] = drop_keep(h1, 1, d.attn_drop_thr) ? sv[a][hh][3] : 0.f;
                     }
                 }
-                const bf16x8 pb = cat44(pack4(sv[a][0]), pack4(sv[a][1]));
+                bf16x8 pb;
+                if (DROP) {
+                    // pairs converted with ONE v_cvt_pk_bf16_f32 each, AFTER the selects: left to itself the compiler converts
+                    // the eight values one by one, selects on the halves and re-packs them with v_perm (20 instructions for 12)
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    u32x4 pk;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const f32x2_t two = {sv[a][hh][2 * e], sv[a][hh][2 * e + 1]};
+                            pk[2 * hh + e] = __builtin_bit_cast(unsigned, __builtin_convertvector(two, bf16x2_t));
+                        }
+                    pb = __builtin_bit_cast(bf16x8, pk);
+                } else {
+                    pb = cat44(pack4(sv[a][0]), pack4(sv[a][1]));
+                }
 #pragma unroll
                 for (int dd = 0; dd < DVT; ++dd) oacc[a][dd] = mfma16(vfr[dd], pb, oacc[a][dd]);
             }
@@ -920,6 +941,9 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 4 : 5)) void k_swin_
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                            const bf16_t* __restrict__ wmlp, const float* __restrict__ bmlp,
                                                            bf16_t* __restrict__ t1_out, bf16_t* __restrict__ y) {
+    // dropout keys of this call (common.hpp drop_seed: uniform, scalar-ALU work; unused without dropout)
+    const uint32_t attn_key = drop_seed(d.attn_seed, d.seed_epoch), proj_key = drop_seed(d.proj_seed, d.seed_epoch);
+    (void)attn_key; (void)proj_key;
     constexpr int KS = (CT + 1) / 2;
     // Wide stages (C >= 96) are bound by fetching the weights: every wave used to pull the whole [C][C] matrix through
     // L1 for its 16 tokens.  There the workgroup's four waves share each 16-row weight slab through LDS (KS sub-tiles of
@@ -997,7 +1021,7 @@ __global__ __launch_bounds__(256, CT >= 12 ? 2 : (CT >= 6 ? 4 : 5)) void k_swin_
             f32x4 keep = {1.f, 1.f, 1.f, 1.f};
             if (d.proj_drop_thr) {                           // proj dropout: on proj(o) + b, before the residual
                 const uint32_t pi = (uint32_t)((tt * C + n0) >> 1);
-                const uint32_t h0 = drop_hash(pi, drop_seed(d.proj_seed, d.seed_epoch)), h1 = drop_hash(pi + 1, drop_seed(d.proj_seed, d.seed_epoch));
+                const uint32_t h0 = drop_hash(pi, proj_key), h1 = drop_hash(pi + 1, proj_key);
                 keep[0] = drop_keep(h0, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
                 keep[1] = drop_keep(h0, 1, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
                 keep[2] = drop_keep(h1, 0, d.proj_drop_thr) ? d.proj_drop_scale : 0.f;
