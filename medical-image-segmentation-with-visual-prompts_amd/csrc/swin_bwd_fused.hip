@@ -367,13 +367,17 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
 
     // dQ of query tile t: the eight waves' partial tiles (buffer t & 1) added in wave order
     auto dq_store = [&](int t) {
-        const float* src = dqp + (size_t)(t & 1) * NW * 256 + r * 16 + 4 * g;
+        // lane (r, g) adds chunk gs = g ^ f(r) of query row r: linear 64-byte rows read with ds_read_b128 in the natural lane
+        // order take twice the passes (tools/ubench/lds_patterns: 0.87 against 0.75 of LDS-active cycles), the chunk rotation of
+        // OperandRows<32> is the conflict-free b128 read order; which lane holds which four head dims is free here
+        const int gs = g ^ ((0 - (r >> 2)) & 3);
+        const float* src = dqp + (size_t)(t & 1) * NW * 256 + r * 16 + 4 * gs;
         f32x4 acc = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
         for (int w = 1; w < NW; ++w) acc = acc + *reinterpret_cast<const f32x4*>(src + w * 256);
         const int qrow = 16 * t + r;
-        if (qrow < Nqp && 4 * g < hd)
-            st4(dq + ((bph * Nqp + qrow) * (long)hd + 4 * g), pack4(acc * MIVP_LN2));      // K carries log2(e)
+        if (qrow < Nqp && 4 * gs < hd)
+            st4(dq + ((bph * Nqp + qrow) * (long)hd + 4 * gs), pack4(acc * MIVP_LN2));     // K carries log2(e)
     };
 
     // lane-constant parts of every LDS address of the tile loop (the t-dependent part is a multiple of the tile stride:
@@ -453,9 +457,20 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
             }
             // partial dQ^T [head dim][query] over this wave's keys: B = dS^T by transposing reads of the slots just written
             // (same wave: ordered by the LDS queue), A = K^T columns of the key tile
+            // Key tiles go in PAIRS through one K = 32 product: a 16x16x16 MFMA costs the matrix pipe and the vector port exactly
+            // what a 16x16x32 one does (tools/ubench/valu_rates.hip), and the chain of dependent accumulations in front of the
+            // barrier is half as long
             f32x4 dqa = fzero4();
+            constexpr int NTQ = ABL == 3 ? 0 : NT;
 #pragma unroll
-            for (int i = 0; i < (ABL == 3 ? 0 : NT); ++i) {
+            for (int i = 0; i + 1 < NTQ; i += 2) {
+                const bf16x8 b = cat44(tr_read(ex_tr + 4096 * i), tr_read(ex_tr + 4096 * (i + 1)));
+                const bf16x8 a = DMA ? cat44(tr_read(kt_rd + 4096 * i), tr_read(kt_rd + 4096 * (i + 1)))
+                                     : cat44(*reinterpret_cast<const bf16x4*>(kt_rd + 256 * i), *reinterpret_cast<const bf16x4*>(kt_rd + 256 * (i + 1)));
+                dqa = mfma16(a, b, dqa);
+            }
+            if (NTQ & 1) {
+                constexpr int i = NTQ > 0 ? NTQ - 1 : 0;
                 const bf16x4 b = tr_read(ex_tr + 4096 * i);
                 const bf16x4 a = DMA ? tr_read(kt_rd + 4096 * i) : *reinterpret_cast<const bf16x4*>(kt_rd + 256 * i);
                 dqa = mfma16k16(a, b, dqa);
