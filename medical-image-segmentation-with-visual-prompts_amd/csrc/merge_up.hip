@@ -47,74 +47,138 @@ MIVP_DEV long merge_src(const MivpMergeDesc& d, const MergeTok& m, int part) {
     return ((m.b * d.dims[0] + xc[0]) * (long)d.dims[1] + xc[1]) * d.dims[2] + xc[2];
 }
 
+// Work split (round 3).  The first form gathered straight into the MFMA B lane map: `if (in bounds) load` per k-step, i.e.
+// KS dependent memory round trips in a row (24 at kC = 768: ~25 of the 32 us of the bottleneck merge), each touching 64
+// different rows per wave instruction.  Now:
+//   1. lane 0..63 decode the workgroup's 64 tokens once (LDS table: first-neighbour voxel, front-pad flags);
+//   2. the 64 x kC/8 sixteen-byte row pieces are loaded PIECE-MAJOR -- adjacent lanes, adjacent pieces of one source row --
+//      unconditionally (clamped address, zeroed afterwards), several in flight per lane, into an LDS row image;
+//   3. LayerNorm runs on the image with four lanes per row (rolled loops: a register-resident row made the compiler hoist
+//      every gamma / beta load of the row, 384 registers at kC = 768);
+//   4. each wave takes its 16 tokens' B fragments from the image and walks the output tiles as before (weight slabs through
+//      LDS, split over gridDim.y where token groups are few).
 template <int KS>
-__global__ __launch_bounds__(256) void k_patch_merge_fwd(MivpMergeDesc d, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, KS >= 24 ? 1 : 2) void k_patch_merge_fwd(MivpMergeDesc d, const bf16_t* __restrict__ x,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          const bf16_t* __restrict__ w, bf16_t* __restrict__ y) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
+    constexpr int K = 32 * KS, ROWB = 2 * K + 16, PPR = K / 8, ROWS = 64;
+    using WS = WeightSlabsRM<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem_pm[];
+    char* img = smem_pm;                                         // [64][kC] bf16 (+16 B per row): gathered, then normalised rows
+    char* wsm = img + ROWS * ROWB;                               // two weight slabs
+    long* tvox = reinterpret_cast<long*>(wsm + WS::BYTES);       // [64] first-neighbour voxel of the token
+    int* tflag = reinterpret_cast<int*>(tvox + ROWS);            // [64] bit a: axis a starts in the front pad; bit 3: live
+    float* gam = reinterpret_cast<float*>(tflag + ROWS);         // [kC] gamma | [kC] beta
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int C = d.C;
-    const int kC = (d.merge_last ? 8 : 4) * C;
-    const long t = ((long)blockIdx.x * 4 + wave) * 16 + r;
-    const MergeTok m = merge_token(d, t);
-
-    float xs[KS][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c = 32 * s + 8 * g;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xs[s][i] = 0.f;
-        if (m.live && c < kC) {
-            const int part = c / C, ch = c - part * C;
-            const long src = merge_src(d, m, part);
-            if (src >= 0) {
-                const bf16x8 raw = ld8(x + src * C + ch);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { xs[s][i] = (float)raw[i]; sum += xs[s][i]; }
-            }
-        }
-    }
-    const float mean = col_sum(sum) / (float)kC;
-    float var = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        if (32 * s + 8 * g < kC) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float dv = xs[s][i] - mean; var += dv * dv; }
-        }
-    }
-    const float rstd = rsqrtf(col_sum(var) / (float)kC + d.ln_eps);
-    bf16x8 xb[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c = 32 * s + 8 * g;
-        bf16x8 yv = zero8();
-        if (m.live && c < kC) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) yv[i] = (bf16_t)((xs[s][i] - mean) * rstd * ln_w[c + i] + ln_b[c + i]);
-        }
-        xb[s] = yv;
-    }
+    const long row0 = (long)blockIdx.x * ROWS;
     // output tiles are split over gridDim.y (the deep stages have only a few dozen token groups)
     const int n_tiles = (d.Cout + 15) / 16;
     const int per_y = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int nt_lo = blockIdx.y * per_y, nt_hi = (nt_lo + per_y) < n_tiles ? (nt_lo + per_y) : n_tiles;
-    // the four waves share each 16-row weight slab through LDS (WeightSlabs, common.hpp): kC is 384 or more here
-    using WS = WeightSlabsRM<KS>;
-    __shared__ __attribute__((aligned(16))) char wsm[WS::BYTES];
-    WS ws;
-    if (nt_lo < nt_hi) { ws.fetch(w, kC, 16 * nt_lo, d.Cout, kC); ws.store(wsm, 0); __syncthreads(); }
+    // nothing below depends on the tokens: the first two weight slabs and gamma / beta travel while the rows are gathered
+    WS ws, ws1;
+    if (nt_lo < nt_hi) ws.fetch(w, K, 16 * nt_lo, d.Cout, K);
+    if (nt_lo + 1 < nt_hi) ws1.fetch(w, K, 16 * (nt_lo + 1), d.Cout, K);
+    for (int c = tid; c < K; c += 256) { gam[c] = ln_w[c]; gam[K + c] = ln_b[c]; }
+    if (tid < ROWS) {
+        const MergeTok m = merge_token(d, row0 + tid);
+        int x0[3], flag = m.live ? 8 : 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            x0[a] = ((a < 2 || d.merge_last) ? 2 * m.o[a] : m.o[a]) - (d.dims[a] & 1);
+            flag |= x0[a] < 0 ? (1 << a) : 0;
+        }
+        tvox[tid] = ((m.b * d.dims[0] + x0[0]) * (long)d.dims[1] + x0[1]) * d.dims[2] + x0[2];
+        tflag[tid] = flag;
+    }
+    __syncthreads();
+    {   // ---- gather, piece-major ----
+        // concat order (c_off8 / c_off4) as bit sets over `part`: the parts that take the second neighbour along h / w / d
+        const unsigned hbits = d.merge_last ? 0xB2u : 0xAu, wbits = d.merge_last ? 0xD4u : 0xCu, dbits = d.merge_last ? 0xE8u : 0u;
+        const int sw = d.dims[2], sh = d.dims[1] * d.dims[2];
+        const FastDiv byC(C), byPPR(PPR);
+        constexpr int NP = ROWS * PPR / 256, BATCH = NP % 12 == 0 ? 12 : (NP % 4 == 0 ? 4 : (NP % 2 == 0 ? 2 : 1));
+        for (int i0 = 0; i0 < NP; i0 += BATCH) {
+            bf16x8 v[BATCH];
+            bool ok[BATCH];
+            int dst[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int P = tid + 256 * (i0 + u);
+                const int row = byPPR.div(P), c = 8 * (P - row * PPR);
+                const int part = byC.div(c), ch = c - part * C;
+                const int oh = (hbits >> part) & 1, ow = (wbits >> part) & 1, od = (dbits >> part) & 1;
+                const int flag = tflag[row];
+                // a front-pad axis is only in bounds for the second neighbour
+                ok[u] = (flag & 8) && ((flag & 1) == 0 || oh) && ((flag & 2) == 0 || ow) && ((flag & 4) == 0 || od);
+                const long vox = sel(ok[u], tvox[row] + oh * sh + ow * sw + od, 0L);
+                v[u] = ld8(x + vox * C + ch);
+                dst[u] = row * ROWB + 2 * c;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) *reinterpret_cast<bf16x8*>(img + dst[u]) = keep_if(v[u], ok[u]);
+        }
+    }
+    if (nt_lo < nt_hi) ws.store(wsm, 0);
+    if (nt_lo + 1 < nt_hi) ws1.store(wsm, 1);
+    __syncthreads();
+    {   // ---- LayerNorm over the kC-long rows: four lanes per row ----
+        const int row = tid >> 2, sub = tid & 3;
+        char* rp = img + row * ROWB + 16 * sub;
+        const bool live = (tflag[row] & 8) != 0;
+        float sum = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < PPR / 4; ++i) {
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(rp + 64 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)raw[e];
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+        const float mean = sum / (float)K;
+        float var = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < PPR / 4; ++i) {
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(rp + 64 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dv = (float)raw[e] - mean; var += dv * dv; }
+        }
+        var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
+        const float rstd = rsqrtf(var / (float)K + d.ln_eps);
+#pragma unroll 2
+        for (int i = 0; i < PPR / 4; ++i) {
+            const int c = 8 * (sub + 4 * i);
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(rp + 64 * i);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(gam + c), w1 = *reinterpret_cast<const f32x4*>(gam + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(gam + K + c), b1 = *reinterpret_cast<const f32x4*>(gam + K + c + 4);
+            bf16x8 yv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yv[e] = (bf16_t)(((float)raw[e] - mean) * rstd * w0[e] + b0[e]);
+                yv[4 + e] = (bf16_t)(((float)raw[4 + e] - mean) * rstd * w1[e] + b1[e]);
+            }
+            *reinterpret_cast<bf16x8*>(rp + 64 * i) = keep_if(yv, live);     // a dead row stays zero (as the B operand)
+        }
+    }
+    __syncthreads();
+    const long t = row0 + 16 * wave + r;
+    const bool live = (tflag[16 * wave + r] & 8) != 0;
+    bf16x8 xb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const bf16x8*>(img + (16 * wave + r) * ROWB + 64 * s + 16 * g);
+    // slab nt + 2 is requested before tile nt is multiplied and stored over slab nt after the barrier that ends the tile
+    // (two tiles of flight time for a load; the products of a tile take a fraction of one memory round trip)
     for (int nt = nt_lo; nt < nt_hi; ++nt) {
         f32x4 acc = fzero4();
         const int cur = (nt - nt_lo) & 1;
-        if (nt + 1 < nt_hi) ws.fetch(w, kC, 16 * (nt + 1), d.Cout, kC);
+        if (nt + 2 < nt_hi) ws.fetch(w, K, 16 * (nt + 2), d.Cout, K);
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = mfma16(WS::frag8(wsm, cur, s, r, 8 * g), xb[s], acc);
-        if (nt + 1 < nt_hi) ws.store(wsm, cur ^ 1);
-        __syncthreads();
         const int n0 = 16 * nt + 4 * g;
-        if (m.live && n0 < d.Cout) st4(y + t * d.Cout + n0, pack4(acc));
+        if (live && n0 < d.Cout) st4(y + t * d.Cout + n0, pack4(acc));
+        __syncthreads();
+        if (nt + 2 < nt_hi) ws.store(wsm, cur);
     }
 }
 
@@ -134,15 +198,23 @@ extern "C" int mivp_patch_merge_fwd(const MivpMergeDesc* d, const void* x, const
     const unsigned gx = (unsigned)((T + 63) / 64);
     const int n_tiles = (d->Cout + 15) / 16;
     // every workgroup repeats the gather + LayerNorm prologue of its 64 tokens, so split the output tiles only as far as
-    // ONE resident round of workgroups goes: 2 per CU for KS = 24 (221 VGPRs), 4 for KS = 12, 8 below
-    const long resident = 256L * (KS >= 24 ? 2 : KS >= 12 ? 4 : 8);
+    // ONE resident round of workgroups goes (the row image sets it: 1 per CU for KS = 24, 2 for KS = 12, ...)
+    const size_t lds = (size_t)64 * (64 * KS + 16) + 2048 * KS + 64 * 12 + 256 * KS;
+    long per_cu = (long)(160 * 1024 / lds);
+    if (per_cu > 8) per_cu = 8;
+    const long resident = 256L * per_cu;
     int ny = (int)(resident / gx);
     if (ny > n_tiles) ny = n_tiles;
     if (ny < 1) ny = 1;
+    while (n_tiles % ny != 0) --ny;                              // equal shares
     const dim3 grid(gx, (unsigned)ny);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_PM(K) hipLaunchKernelGGL((k_patch_merge_fwd<K>), grid, dim3(256), 0, st, *d, (const bf16_t*)x, ln_w, ln_b, \
-                                         (const bf16_t*)w, (bf16_t*)y)
+#define LAUNCH_PM(K)                                                                                                          \
+    do {                                                                                                                      \
+        MIVP_LDS_OPT_IN(k_patch_merge_fwd<K>, lds);                                                                           \
+        hipLaunchKernelGGL((k_patch_merge_fwd<K>), grid, dim3(256), lds, st, *d, (const bf16_t*)x, ln_w, ln_b,                \
+                           (const bf16_t*)w, (bf16_t*)y);                                                                     \
+    } while (0)
     switch (KS) {
         case 1: LAUNCH_PM(1); break;
         case 2: LAUNCH_PM(2); break;
