@@ -324,7 +324,7 @@ size_t mivp_conv3d_fwd_ws(const MivpConvDesc* d);
 int mivp_conv3d_halo_supported(const MivpConvDesc* d);
 int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const void* wh, const float* bias,
                          const float* scale, const float* shift /* prologue, NULL unless d->pro_affine */,
-                         const void* residual /* NULL unless d->add_residual */, void* y, int32_t brick_w /* 8: 4x8x16 bricks, 8 waves; 4: 4x4x16 bricks, 4 waves; 6: 6x6x16 bricks, 12 waves */, mivp_stream_t stream);
+                         const void* residual /* NULL unless d->add_residual */, void* y, int32_t brick_w /* 8: 4x8x16 bricks, 8 waves; 4: 4x4x16 bricks, 4 waves; 6: 6x6x16 bricks, 12 waves; 66: 6x6x8 and 36: 3x6x8 bricks of 2x8-voxel tiles (6 / 3 waves) */, mivp_stream_t stream);
 /* Segmentation-head forward (swin_unetr.py:229-237): y = conv3x3x3(x * scale + shift) + bias for 27*Cout <= 64
  * (Cout <= 2), Cin + 1 <= 64.  x [B,H,W,D,Cin] bf16 (pre-BatchNorm), w f32 [Cout][Cin][3][3][3] (the nn.Conv3d
  * weight as stored), scale/shift f32 [Cin] (BatchNorm as an affine), y f32 [B,H,W,D,Cout].

@@ -31,22 +31,34 @@ namespace {
 //                                    brick would mostly pad)
 //   6 x 6 x 16, 12 waves x 3 tiles  (576 voxels: 48^3 x 4 volumes are 768 such bricks = exactly three per CU, where the
 //                                    864 4x8x16 bricks need a fourth, 3/8-full round)
-constexpr int HB_D = 16, HD = HB_D + 2;
 constexpr int KSTEPS = 14;                                    // 28 taps (27 + one zero tap) x 16 channels / 32
-template <int BH, int BW, int TPW>
+// Deep decoder stages (round 3): 12 x 12 x 24 and 6 x 6 x 24 volumes.  With 16 voxels of a tile along d a 24-deep axis is
+// covered by two tiles (25 % padding) and the 4 x 8 / 4 x 4 bricks pad h and w as well: the dec2 conv ran 44 % of its
+// MFMAs on padding, on 192 of 256 CUs.  BD = 8 bricks use tiles of 2 (w) x 8 (d) voxels -- the halo rows of a tile are then
+// two runs of 8 -- and divide those volumes exactly:
+//   6 x 6 x 8, 6 waves x 3 tiles    (288 voxels; dec2: 48 bricks x 4 channel groups)
+//   3 x 6 x 8, 3 waves x 3 tiles    (144 voxels; bottleneck: 24 bricks x 8 channel groups)
+template <int BH, int BW, int TPW, int BD = 16>
 struct HaloGeom {
+    // HD: halo rows along d as laid out in LDS.  The 2 x 8 tiles read two runs of 8 rows HD apart; with HD = 16 (10 used) the
+    // second run falls in the bank windows the first one leaves free (rows r and r + 8 take opposite 16-byte halves in a
+    // ds_read_b128 service group, see the top of the file); packed at 10 the two runs collide two-way
+    static constexpr int HB_D = BD, HD_USED = BD + 2, HD = BD == 8 ? 16 : BD + 2;
+    static constexpr int TW = BD == 8 ? 2 : 1;                  // w columns of a voxel tile
     static constexpr int HH = BH + 2, HW = BW + 2;
     static constexpr int HROWS = HH * HW * HD;                 // 1080 (4x8) / 648 (4x4) / 1152 (6x6)
     static constexpr int HALO_BYTES = HROWS * 32;
-    static constexpr int WAVES = BH * BW / TPW, TILES = TPW;
+    static constexpr int WAVES = BH * (BW / TW) / TPW, TILES = TPW;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int HPIECES = (HROWS * 2 + THREADS - 1) / THREADS;   // 16-byte halo pieces per thread
-    static_assert(BW % TPW == 0, "a wave's tiles stay in one brick row");
+    static_assert(BW % (TW * TPW) == 0, "a wave's tiles stay in one brick row");
 };
 template <int BRICK> struct BrickOf;
 template <> struct BrickOf<8> { using G = HaloGeom<4, 8, 4>; };
 template <> struct BrickOf<4> { using G = HaloGeom<4, 4, 4>; };
 template <> struct BrickOf<6> { using G = HaloGeom<6, 6, 3>; };
+template <> struct BrickOf<66> { using G = HaloGeom<6, 6, 3, 8>; };
+template <> struct BrickOf<36> { using G = HaloGeom<3, 6, 3, 8>; };
 
 // 16 zero bytes in global memory: the LDS-DMA source of halo pieces outside the volume
 __device__ __attribute__((aligned(16))) unsigned int g_halo_zero[4] = {0u, 0u, 0u, 0u};
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
                                                           const bf16_t* __restrict__ residual, bf16_t* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GEO = typename BrickOf<BRICK>::G;
-    constexpr int HB_H = GEO::HH - 2, HB_W = GEO::HW - 2, TPW = GEO::TILES;
+    constexpr int HB_H = GEO::HH - 2, HB_W = GEO::HW - 2, TPW = GEO::TILES, HB_D = GEO::HB_D, HD = GEO::HD, TW = GEO::TW;
     constexpr int HW = GEO::HW, HROWS = GEO::HROWS, HALO_BYTES = GEO::HALO_BYTES, HTHREADS = GEO::THREADS, HPIECES = GEO::HPIECES;
     constexpr int BN = 16 * NTN;
     constexpr int WBYTES = KSTEPS * BN * 64;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
             const int hd = row % HD, hw = (row / HD) % HW, hh = row / (HD * HW);
             const int gh = h0 + hh - 1, gw = w0 + hw - 1, gd = d0 + hd - 1;
             hdst[u] = halo_off(row, half);
-            if ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && (unsigned)gd < (unsigned)D)
+            if ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && (unsigned)gd < (unsigned)D && hd < GEO::HD_USED)
                 hsrc[u] = ((((long)b * H + gh) * W + gw) * D + gd) * Cin + 8 * half;
         }
     }
@@ -191,12 +203,14 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
     };
 
     // ---- this wave's TPW voxel tiles: brick rows (th, tw_i), 16 voxels along d; byte offset of voxel r of tile i at tap 0
-    constexpr int WPR = HB_W / TPW;                               // waves per brick row
-    const int th = wave / WPR, tw0 = (wave % WPR) * TPW;
+    constexpr int WPR = HB_W / (TW * TPW);                        // waves per brick row
+    const int th = wave / WPR, tw0 = (wave % WPR) * TPW * TW;
     const int half = g & 1, tsel = g >> 1;
+    // voxel r of a tile: (w, d) = (0, r) for the 1 x 16 tiles, (r >> 3, r & 7) for the 2 x 8 ones
+    const int rw = TW == 2 ? (r >> 3) : 0, rd = TW == 2 ? (r & 7) : r;
     int vbyte[TPW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) vbyte[i] = halo_off(((th * HW) + (tw0 + i)) * HD + r, half);
+    for (int i = 0; i < TPW; ++i) vbyte[i] = halo_off(((th * HW) + (tw0 + TW * i + rw)) * HD + rd, half);
     // weight fragment: row (16nt + r) of k-step j, chunk g under the row swizzle (constant per lane: j*BN and 16nt are multiples of 16)
     const int wbyte = r * 64 + 16 * wswz(r, g);
 
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
     }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int gh = h0 + th, gw = w0 + tw0 + i, gd = d0 + r;
+        const int gh = h0 + th, gw = w0 + tw0 + TW * i + rw, gd = d0 + rd;
         ok[i] = gh < H && gw < W && gd < D;
         voff[i] = ((((long)b * H + gh) * W + gw) * D + gd) * d.Cout;
 #pragma unroll
@@ -303,10 +317,11 @@ __global__ __launch_bounds__(BrickOf<BRICK>::G::THREADS) void k_conv3d_halo(Mivp
             const int p = p0 + lane;
             if (p < TPW * 16 * SEG) {
                 const int vox = p / SEG, seg = p - vox * SEG, i = vox >> 4, rr = vox & 15;
-                const bool inside = (h0 + th) < H && (w0 + tw0 + i) < W && (d0 + rr) < D;
+                const int ow = TW * i + (TW == 2 ? (rr >> 3) : 0), od = TW == 2 ? (rr & 7) : rr;
+                const bool inside = (h0 + th) < H && (w0 + tw0 + ow) < W && (d0 + od) < D;
                 if (inside) {
                     const bf16x8 piece = *reinterpret_cast<const bf16x8*>(ost + (size_t)vox * (BN * 2) + 16 * seg);
-                    st8(y + (row0 + (long)i * D + rr) * d.Cout + co_base + 8 * seg, piece);
+                    st8(y + (row0 + (long)ow * D + od) * d.Cout + co_base + 8 * seg, piece);
                 }
             }
         }
@@ -351,14 +366,19 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     MIVP_REQUIRE(d && x && wh && y);
     MIVP_REQUIRE(!d->pro_affine || (scale && shift));
     MIVP_REQUIRE((d->add_residual != 0) == (residual != nullptr));
-    MIVP_REQUIRE(brick_w == 4 || brick_w == 8 || brick_w == 6);
+    MIVP_REQUIRE(brick_w == 4 || brick_w == 8 || brick_w == 6 || brick_w == 66 || brick_w == 36);
     if (!mivp_conv3d_halo_supported(d)) { mivp_set_error("conv3d_halo_fwd: shape outside the halo kernel's window"); return MIVP_EUNSUPPORTED; }
     const int groups = (d->Cout + 47) / 48;
     const int ntn = groups > 1 ? 3 : (d->Cout + 15) / 16;
-    const int bh = brick_w == 6 ? 6 : 4;
-    const long bricks = (long)d->B * ((d->dims[0] + bh - 1) / bh) * ((d->dims[1] + brick_w - 1) / brick_w) *
-                        ((d->dims[2] + HB_D - 1) / HB_D);
-    const size_t halo_bytes = brick_w == 8 ? BrickOf<8>::G::HALO_BYTES : (brick_w == 4 ? BrickOf<4>::G::HALO_BYTES : BrickOf<6>::G::HALO_BYTES);
+    // brick codes: 8 = 4 x 8 x 16, 4 = 4 x 4 x 16, 6 = 6 x 6 x 16; 66 = 6 x 6 x 8 and 36 = 3 x 6 x 8 (tiles of 2 x 8 voxels)
+    const int bh = brick_w == 6 || brick_w == 66 ? 6 : (brick_w == 36 ? 3 : 4);
+    const int bwid = brick_w == 66 || brick_w == 36 ? 6 : brick_w;
+    const int bd = brick_w == 66 || brick_w == 36 ? 8 : 16;
+    const long bricks = (long)d->B * ((d->dims[0] + bh - 1) / bh) * ((d->dims[1] + bwid - 1) / bwid) *
+                        ((d->dims[2] + bd - 1) / bd);
+    const size_t halo_bytes = brick_w == 8 ? BrickOf<8>::G::HALO_BYTES : brick_w == 4 ? BrickOf<4>::G::HALO_BYTES
+                            : brick_w == 6 ? BrickOf<6>::G::HALO_BYTES : brick_w == 66 ? BrickOf<66>::G::HALO_BYTES
+                                                                                       : BrickOf<36>::G::HALO_BYTES;
     const size_t lds = 2 * (halo_bytes + (size_t)KSTEPS * 16 * ntn * 64) + (d->pro_affine ? (size_t)2 * d->Cin * sizeof(float) : 0);
     if (lds > 160 * 1024) { mivp_set_error("conv3d_halo_fwd: LDS budget exceeded"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
@@ -377,7 +397,9 @@ extern "C" int mivp_conv3d_halo_fwd(const MivpConvDesc* d, const void* x, const 
     } while (0)
     if (brick_w == 8) HALO_BRICK(8);
     else if (brick_w == 4) HALO_BRICK(4);
-    else HALO_BRICK(6);
+    else if (brick_w == 6) HALO_BRICK(6);
+    else if (brick_w == 66) HALO_BRICK(66);
+    else HALO_BRICK(36);
 #undef HALO_BRICK
 #undef HALO_LAUNCH
     return mivp_check_launch("conv3d_halo_fwd");

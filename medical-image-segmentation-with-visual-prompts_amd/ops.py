@@ -88,24 +88,26 @@ def halo_pack(wp: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
     return wh
 
 
-# halo-brick kernel geometries: code -> (brick h, brick w, voxel tiles per SIMD and k-step)
-_HALO_BRICKS = {8: (4, 8, 8), 4: (4, 4, 4), 6: (6, 6, 9)}
+# halo-brick kernel geometries: code -> (brick h, brick w, brick d, voxel tiles of the busiest SIMD per k-step)
+_HALO_BRICKS = {8: (4, 8, 16, 8), 4: (4, 4, 16, 4), 6: (6, 6, 16, 9), 66: (6, 6, 8, 6), 36: (3, 6, 8, 3)}
 
 
 def halo_brick(B, dims, cout) -> int:
-    """Brick code (8: 4x8x16, 4: 4x4x16, 6: 6x6x16) for the halo-brick kernel, 0 for the im2col kernel (tiny volumes).
+    """Brick code (8: 4x8x16, 4: 4x4x16, 6: 6x6x16; 66: 6x6x8 and 36: 3x6x8 with voxel tiles of 2 x 8 instead of 1 x 16) for
+    the halo-brick kernel, 0 for the im2col kernel (tiny volumes).
     One 128-160 KB workgroup fits a CU, so the cost model is rounds = ceil(workgroups / 256) times the work a SIMD does
     per k-step of one workgroup (+1 for the per-chunk staging / barrier cost); ties go to the smaller brick.  At 48^3 x 4
-    the 6x6x16 brick gives 768 workgroups = exactly three rounds where 4x8x16 needs 864 = a fourth, 3/8-full one;
-    measured on the decoder shapes with tools/bench_conv.py."""
+    the 6x6x16 brick gives 768 workgroups = exactly three rounds where 4x8x16 needs 864 = a fourth, 3/8-full one; the
+    8-deep bricks divide the 12 x 12 x 24 and 6 x 6 x 24 volumes of the deep decoder stages exactly (145 -> 110 us and
+    70 -> 54 us there, tools/ab_conv_bricks.py); measured on the decoder shapes with tools/bench_conv.py."""
     H, W, D = dims
     if B * H * W * D < 1024:
         return 0
     groups = (cout + 47) // 48
     best, best_cost = 0, None
-    for code in (4, 8, 6):
-        bh, bw, tiles = _HALO_BRICKS[code]
-        wgs = B * ((H + bh - 1) // bh) * ((W + bw - 1) // bw) * ((D + 15) // 16) * groups
+    for code in (4, 8, 6, 36, 66):
+        bh, bw, bd, tiles = _HALO_BRICKS[code]
+        wgs = B * ((H + bh - 1) // bh) * ((W + bw - 1) // bw) * ((D + bd - 1) // bd) * groups
         cost = ((wgs + 255) // 256) * (tiles + 1)
         if best_cost is None or cost < best_cost:
             best, best_cost = code, cost

@@ -51,15 +51,26 @@ def test_conv3d_halo_brick_kernel(cin, cout, dims, bias):
     y = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=8)
     y4 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=4)      # 4x4x16 bricks, 4 waves
     y6 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=6)      # 6x6x16 bricks, 12 waves x 3 tiles
-    y_ref = ops.conv3d(cl(x), wp, bd, cout, residual=rd)    # tiny volume -> the im2col kernel
+    y66 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=66)    # 6x6x8 bricks of 2 x 8 voxel tiles, 6 waves x 3 tiles
+    y36 = ops.conv3d(cl(x), wp, bd, cout, residual=rd, force_halo=36)    # 3x6x8 bricks of 2 x 8 voxel tiles, 3 waves x 3 tiles
+    saved = ops.halo_brick
+    ops.halo_brick = lambda *a: 0
+    try:
+        y_ref = ops.conv3d(cl(x), wp, bd, cout, residual=rd)    # the im2col kernel
+    finally:
+        ops.halo_brick = saved
     torch.cuda.synchronize()
     assert getattr(wp, "_mivp_halo", None) is not None     # the halo path really ran
-    assert rel_l2(cf(y), want) < 4e-3 and rel_l2(cf(y4), want) < 4e-3 and rel_l2(cf(y6), want) < 4e-3
-    assert rel_l2(cf(y), cf(y_ref)) < 2e-3 and rel_l2(cf(y4), cf(y_ref)) < 2e-3 and rel_l2(cf(y6), cf(y_ref)) < 2e-3
+    for got in (y, y4, y6, y66, y36):
+        assert rel_l2(cf(got), want) < 4e-3 and rel_l2(cf(got), cf(y_ref)) < 2e-3
+    # every brick geometry adds the same products in the same order (chunk, k-step): identical bits
+    for got in (y4, y6, y66, y36):
+        assert torch.equal(got, y)
 
 
 @pytest.mark.parametrize("cin,cout,dims,lrelu,bw", [(144, 48, (9, 13, 21), True, 8), (32, 96, (6, 6, 24), False, 4),
-                                                    (144, 48, (13, 9, 21), True, 6)])
+                                                    (144, 48, (13, 9, 21), True, 6), (64, 48, (7, 12, 21), True, 66),
+                                                    (32, 96, (6, 6, 24), True, 36)])
 def test_conv3d_halo_fused_prologue(cin, cout, dims, lrelu, bw):
     """BatchNorm affine (+ LeakyReLU) applied while the halo is staged: zero padding stays zero AFTER the activation."""
     from mivp_amd import ops
