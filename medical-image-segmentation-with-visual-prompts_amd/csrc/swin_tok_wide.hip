@@ -235,6 +235,139 @@ __global__ __launch_bounds__(256, CT <= 3 ? 4 : (CT <= 12 ? 3 : 2)) void k_qkv_f
 }
 
 // ---------------------------------------------------------------------------------------------
+// gather + LayerNorm + QKV, WEIGHT-STATIONARY form for C = 96 / 192 (round 3)
+// k_qkv_fwd_wide streams the whole 6 C^2-byte fragment image through every workgroup of 32 (C = 192) or 64 tokens: at
+// stage 2 that is 704 x 221 KB = 155 MB of L2 reads per launch for 31 MB of tensors, and the launch ran at the L2's ~8 TB/s
+// (19.4 us).  Its [ROWS][3C] output image (the head-major q | k | v chunks are written from it) is also what keeps it at
+// 32 rows.  Here a workgroup owns 64 tokens, a wave a set of column-tile PAIRS (32 output channels = one head at
+// head_dim 32): the pair's 2 KS weight fragments sit in registers (the next pair's travel meanwhile) and the four token
+// tiles pass under them, B fragments from the LDS row image (one read per two MFMAs).  The accumulators leave from the
+// MFMA lane map -- lane (r, g): token r, channels 4 g .. 4 g + 3 -- as 8-byte pieces: 16 tokens x 32 contiguous bytes per
+// store, the two tiles of a pair completing 64-byte head rows.  No output image, no second index decode, half (C = 192)
+// the weight traffic, LDS = the 64 x C input image only.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+MIVP_DEV void ws_load_pair(const bf16_t* __restrict__ wqkv, int pair, int lane, bf16x8 (&a)[2][KS]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[t][s] = wfrag(wqkv, KS, 2 * pair + t, s, lane);
+}
+// one column-tile pair of k_qkv_fwd_ws: the four token tiles under the pair's fragments, stores from the MFMA lane map
+template <int KS>
+struct WsOut {
+    const char* Ximg;
+    bf16_t* q;
+    long to_k, to_v;                                              // k - q, v - q (one global pointer: a select between three decays to flat)
+    long head_stride, row0, T;
+    float q_scale;
+    int hd, r, g, heads, Nqp;
+    unsigned bp0, slot0;                                          // window and slot of the workgroup's first row (Nqp >= 64: one wrap at most)
+    template <int C>
+    MIVP_DEV void run(int pair, const bf16x8 (&a)[2][KS]) const {
+        using XI = RowImg<C>;
+        // channels of the pair: tile t covers n0 = 32 pair + 16 t + 4 g .. + 3 of the 3 C outputs
+        long off[2];
+        float sc[2];
+        const FastDiv by_hd(hd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n0 = 32 * pair + 16 * t + 4 * g;
+            const int tensor = n0 >= 2 * C ? 2 : (n0 >= C ? 1 : 0), cc = n0 - tensor * C;
+            const int head = by_hd.div(cc);
+            off[t] = head * head_stride + (cc - head * hd) + sel(tensor == 0, 0L, sel(tensor == 1, to_k, to_v));
+            sc[t] = tensor == 0 ? q_scale : (tensor == 1 ? MIVP_LOG2E : 1.0f);      // K carries log2(e): common.hpp
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4 c0 = fzero4(), c1 = fzero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 b = XI::frag(Ximg, 16 * tt + r, 32 * s + 8 * g);
+                c0 = mfma16(a[0][s], b, c0);
+                c1 = mfma16(a[1][s], b, c1);
+            }
+            // token r of token tile tt: head-0 element offset in a q / k / v tensor
+            unsigned slot = slot0 + 16 * tt + r, bp = bp0;
+            if (slot >= (unsigned)Nqp) { slot -= (unsigned)Nqp; ++bp; }
+            const long tbase = ((long)bp * heads * Nqp + slot) * hd;
+            if (row0 + 16 * tt + r < T) {
+                st4(q + tbase + off[0], pack4(c0 * sc[0]));
+                st4(q + tbase + off[1], pack4(c1 * sc[1]));
+            }
+        }
+    }
+};
+template <int CT>
+__global__ __launch_bounds__(256, CT <= 6 ? 3 : 2) void k_qkv_fwd_ws(MivpSwinDesc d, const bf16_t* __restrict__ x, const int* __restrict__ tok_src,
+                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        const bf16_t* __restrict__ wqkv, bf16_t* __restrict__ q,
+                                                        bf16_t* __restrict__ k, bf16_t* __restrict__ v) {
+    using G = WideGeom<CT>;
+    constexpr int C = G::C, KS = G::KS, ROWS = 64, TPR = 4, XPT = C / 8 / TPR, NPAIR = 3 * CT / 2;
+    using XI = RowImg<G::KP>;
+    static_assert(G::KP == C && C % 32 == 0, "whole k-steps");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ximg = smem;                                           // [64][C]  LayerNorm output (the GEMM's B operand)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * ROWS;
+    // the first pair's fragments do not depend on the rows: they travel during the gather
+    bf16x8 a0[2][KS], a1[2][KS];
+    ws_load_pair<KS>(wqkv, wave, lane, a0);
+    {   // ---- rows: gather, LayerNorm ----
+        const int row = tid / TPR, sub = tid % TPR;
+        const RowTok ti = row_token(d, row0 + row);
+        const int src = sel(ti.live, tok_src[ti.pw * d.Nqp + ti.slot], -2);
+        const long xoff = (ti.b * d.vol_in + max(src, 0)) * (long)C;
+        bf16x8 xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) xr[i] = ld8(x + xoff + 8 * (sub + TPR * i));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            xr[i] = keep_if(xr[i], src >= 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)xr[i][e];
+        }
+        const float mean = row_sum<TPR>(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dvv = (float)xr[i][e] - mean; var += dvv * dvv; }
+        const float rstd = rsqrtf(row_sum<TPR>(var) / (float)C + d.ln_eps);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = 8 * (sub + TPR * i);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ln_w + c), w1 = *reinterpret_cast<const f32x4*>(ln_w + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_b + c), b1 = *reinterpret_cast<const f32x4*>(ln_b + c + 4);
+            bf16x8 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (bf16_t)(((float)xr[i][e] - mean) * rstd * w0[e] + b0[e]);
+                y[4 + e] = (bf16_t)(((float)xr[i][4 + e] - mean) * rstd * w1[e] + b1[e]);
+            }
+            XI::put8(Ximg, row, c, keep_if(y, src >= -1));       // -1: a zero-pad token still goes through LN (-> beta)
+        }
+    }
+    const int hd = C / d.heads;
+    const unsigned bp0 = (unsigned)(row0 / d.Nqp);
+    __syncthreads();
+    const WsOut<KS> out{Ximg, q, k - q, v - q, (long)d.Nqp * hd, row0, (long)d.B * d.P * d.Nqp, d.q_scale, hd, r, g, d.heads, d.Nqp,
+                        bp0, (unsigned)(row0 - (long)bp0 * d.Nqp)};
+    // pairs wave, wave + 4, ...: two register sets, the next pair's loads issued before the current pair is multiplied
+    for (int pair = wave; pair < NPAIR; pair += 8) {
+        if (pair + 4 < NPAIR) ws_load_pair<KS>(wqkv, pair + 4, lane, a1);
+        out.template run<C>(pair, a0);
+        if (pair + 4 < NPAIR) {
+            if (pair + 8 < NPAIR) ws_load_pair<KS>(wqkv, pair + 8, lane, a0);
+            out.template run<C>(pair + 4, a1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // proj + residual -> LayerNorm -> Linear + residual -> scatter          [k_swin_proj_mlp_fwd, swin_fwd.hip]
 // (no proj dropout here: the launcher leaves those calls to the 16-token kernel)
 // ---------------------------------------------------------------------------------------------
@@ -864,6 +997,19 @@ int mivp_tok_wide_qkv_fwd(const MivpSwinDesc* d, const void* x, const int32_t* t
         hipLaunchKernelGGL((k_qkv_fwd_wide<CTV>), WIDE_GRID(CTV), dim3(256), lds, st, *d, (const bf16_t*)x, tok_src, ln_w,   \
                            ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v);                                   \
     } while (0)
+    static const bool no_ws = getenv("MIVP_QKV_FWD_STREAMED_WEIGHTS") != nullptr;      // A/B switch: the round-2 work split
+    const int hd = d->C / d->heads;
+    if (!no_ws && (d->C == 96 || d->C == 192) && hd % 4 == 0 && d->Nqp % 16 == 0 && d->Nqp >= 64) {
+#define L_WS(CTV)                                                                                                            \
+    do {                                                                                                                     \
+        const size_t lds = (size_t)64 * RowImg<WideGeom<CTV>::KP>::ROWB;                                                     \
+        hipLaunchKernelGGL((k_qkv_fwd_ws<CTV>), dim3((unsigned)((T + 63) / 64)), dim3(256), lds, st, *d, (const bf16_t*)x,   \
+                           tok_src, ln_w, ln_b, (const bf16_t*)wqkv, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v);                    \
+    } while (0)
+        if (d->C == 96) L_WS(6); else L_WS(12);
+#undef L_WS
+        return mivp_check_launch("swin_qkv_fwd(weight-stationary)");
+    }
     ROWS_SWITCH(L_W)
 #undef L_W
     return mivp_check_launch("swin_qkv_fwd(wide)");
