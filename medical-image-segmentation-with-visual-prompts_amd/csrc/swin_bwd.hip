@@ -232,8 +232,10 @@ struct AttnBwdGeom {
     static constexpr int VROWB = (DVP + 8) * 2;             // bytes per V/dO row
 };
 
+// (DKS = 2, head_dim 24 / 32: capped at 128 VGPRs -- 5 to 12 spilled dwords outside the key loop -- for the second workgroup per
+//  CU the 78 KB LDS budget below is sized for: 96 -> 81 us un-shifted, 122 -> 102 us shifted at 24^3 x 4, round 3)
 template <int DKS, int DVT, int QPW, int NW, bool DROP, bool MASKED>
-__global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP) ? 4 : 2) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(64 * NW, (DKS <= 2 && !DROP) ? 4 : 2) void k_win_attn_bwd_dq(MivpSwinDesc d, int chunk_tiles, const bf16_t* __restrict__ q,
                                                          const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                          const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka,
@@ -1201,11 +1203,18 @@ extern "C" int mivp_win_attn_bwd_dkv(const MivpSwinDesc* d, const void* q, const
     int dks, nt;
     if (mivp_attn_tile_config(d, &dks, &nt)) { mivp_set_error("win_attn_bwd_dkv: shape outside the instantiated set"); return MIVP_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
+    // The shifted head_dim 24 / 32 kernel runs one workgroup per CU whatever its key-tile count per wave (162 VGPRs at two): with
+    // three tiles per wave a 7^3 window's 22 key tiles are ONE workgroup instead of two that each stage every query row
+    const int ktiles_all = d->Nkp / 16 - ((dk && dv) ? 0 : d->Nqp / 16);
+    const bool three_tiles = ktiles_all > 16 && ktiles_all <= 24;
 #define DKV_ARGS d, q, k, v, kp, vp, qa, ka, tok_rid, d_o, lse, delta, dk, dv, dkp_part, dvp_part, dtok_part, dka_part, st
 #define DKV_PICK3(AUGV, DROPV, MV)                                              \
     do {                                                                        \
         if (dks == 1) return launch_dkv<1, 1, 2, AUGV, DROPV, MV>(DKV_ARGS);    \
+        if (dks == 2 && three_tiles) return launch_dkv<2, 2, (MV && !AUGV && !DROPV) ? 3 : 2, AUGV, DROPV, MV>(DKV_ARGS); \
         if (dks == 2) return launch_dkv<2, 2, 2, AUGV, DROPV, MV>(DKV_ARGS);    \
+        if (three_tiles && !MV && !AUGV && !DROPV) return launch_dkv<3, 3, (!MV && !AUGV && !DROPV) ? 3 : 1, AUGV, DROPV, MV>(DKV_ARGS); \
+        if (ktiles_all > 8 && MV && !AUGV && !DROPV) return launch_dkv<3, 3, (MV && !AUGV && !DROPV) ? 2 : 1, AUGV, DROPV, MV>(DKV_ARGS); \
         return launch_dkv<3, 3, 1, AUGV, DROPV, MV>(DKV_ARGS);                  \
     } while (0)
 #define DKV_PICK(AUGV, DROPV) do { if (d->has_mask) DKV_PICK3(AUGV, DROPV, true); else DKV_PICK3(AUGV, DROPV, false); } while (0)

@@ -99,6 +99,9 @@ def test_block_backward_golden_shapes(tag):
     ((7, 7, 7), (6, 6, 24), 192, 16, 64, (3, 3, 3), True),
     ((7, 7, 7), (12, 12, 24), 96, 4, 0, (3, 3, 3), True),       # decoder, hd 24, no prompts
     ((7, 7, 7), (6, 6, 24), 192, 4, 64, (3, 3, 3), True),       # decoder with prompts, hd 48 (chunked LDS)
+    ((7, 7, 7), (12, 12, 24), 96, 4, 0, (0, 0, 0), True),       # hd 24 un-shifted: the dq pass at two workgroups per CU
+    ((7, 7, 7), (6, 6, 24), 192, 4, 0, (3, 3, 3), True),        # hd 48 without prompts: 22 key tiles, two per wave in the shifted dkv pass
+    ((7, 7, 7), (6, 6, 24), 192, 4, 0, (0, 0, 0), True),        # ... three per wave (one workgroup per window and head) un-shifted
     ((8, 8, 4), (16, 16, 8), 48, 4, 64, (4, 4, 2), True),
 ])
 def test_block_backward_real_sizes(window, dims, C, heads, n_prompt, shift, need_dx):
