@@ -14,9 +14,9 @@ model = [  # (name substring, launches per step, bytes per step, what)
     ("k_patch_embed<1", 1, x_in + a0, "conv_k2s2 + BN apply: reads the volume, writes 48-channel tokens"),
     ("k_swin_qkv_fwdILi2", 4, 4 * (a0 + 3 * rows0 * 24 * 4), "C = 48 gather + LN + QKV: reads x, writes q | k | v (24-byte rows)"),
     ("k_proj_mlp_fwd_wideILi3", 4, 4 * (rows0 * 96 + 2 * a0), "C = 48 proj + MLP: reads o and x, writes y"),
-    ("k_qkv_fwd_wideILi6", 4, 4 * (a1 + 3 * rows1 * 192), "C = 96 QKV"),
+    ("k_qkv_fwd_wsILi6", 4, 4 * (a1 + 3 * rows1 * 192), "C = 96 QKV (weight-stationary form, round 3; was k_qkv_fwd_wide<6>: 24.0 us per launch)"),
     ("k_proj_mlp_fwd_wideILi6", 4, 4 * (rows1 * 192 + 2 * a1), "C = 96 proj + MLP"),
-    ("k_qkv_fwd_wideILi12", 4, 4 * (a2 + 3 * rows2 * 384), "C = 192 QKV"),
+    ("k_qkv_fwd_wsILi12", 4, 4 * (a2 + 3 * rows2 * 384), "C = 192 QKV (weight-stationary form; was k_qkv_fwd_wide<12>: 19.4 us per launch at 155 MB of L2 weight reads)"),
     ("k_proj_mlp_fwd_wideILi12", 4, 4 * (rows2 * 384 + 2 * a2), "C = 192 proj + MLP"),
     ("k_patch_merge_fwdILi12", 2, (a0 + a1) + (a1 + a2), "patch merging enc0 -> enc1, enc1 -> enc2"),
     ("k_patch_merge_fwdILi24", 1, a2 + a3, "patch merging enc2 -> bottleneck"),
