@@ -390,6 +390,16 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
     const int row = tid / TPR, sub = tid % TPR;                  // the row phases' lane map
     const RowTok ti = row_token(d, row0 + row);
     constexpr bool FLAT = flat_rows<CT>();
+    // C = 96: the wave's weight fragments of a GEMM are requested a phase EARLY (proj: before the rows come in, MLP: before the
+    // LayerNorm) -- read in the k loop each GEMM started with an L2 round trip that nothing overlapped
+    constexpr bool PREW = CT == 6;                   // (measured: C = 96 15.9 -> 15.0 us; C = 192 neutral at 46 more registers; C = 384 spills)
+    bf16x8 wa[PREW ? NCT : 1][PREW ? KS : 1];
+    if constexpr (PREW) {
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wa[j][s] = wfrag(wproj, KS, (wave % NCG) + NCG * j, s, lane);
+    }
     int src = -2, dst = -1;
     int fdst[XPT], fb[XPT];                                      // FLAT: scatter target and batch index of this thread's pieces
     if (!FLAT) {
@@ -446,7 +456,8 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
             f32x4 a0 = fzero4(), a1 = fzero4();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a = wfrag(wproj, KS, nt, s, lane);
+                bf16x8 a;
+                if constexpr (PREW) a = wa[j][s]; else a = wfrag(wproj, KS, nt, s, lane);
                 a0 = mfma16(a, RI::frag(Aimg, R0, 32 * s + 8 * g), a0);
                 a1 = mfma16(a, RI::frag(Aimg, R1, 32 * s + 8 * g), a1);
             }
@@ -461,6 +472,12 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
             RI::put4(Ximg, R0, n0, pack4(a0));                  // in place: this lane just read these eight bytes
             RI::put4(Ximg, R1, n0, pack4(a1));
         }
+    }
+    if constexpr (PREW) {
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wa[j][s] = wfrag(wmlp, KS, cg + NCG * j, s, lane);
     }
     __syncthreads();
     {   // ---- rows: t1 out, LayerNorm(t1) -> Aimg ----
@@ -503,7 +520,8 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
             f32x4 a0 = fzero4(), a1 = fzero4();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a = wfrag(wmlp, KS, nt, s, lane);
+                bf16x8 a;
+                if constexpr (PREW) a = wa[j][s]; else a = wfrag(wmlp, KS, nt, s, lane);
                 a0 = mfma16(a, RI::frag(Aimg, R0, 32 * s + 8 * g), a0);
                 a1 = mfma16(a, RI::frag(Aimg, R1, 32 * s + 8 * g), a1);
             }
