@@ -52,7 +52,7 @@ MIVP_DEV float gram_w(int p, int m, int n) {                 // (U^T U)[p][p+m] 
 // q[d] = g2(-1) A[d-1] + g2(0) A[d] + g2(+1) A[d+1].  A thread owns a (b, p0, p1, 8-channel group) line and slides
 // along a segment of d keeping the last three A's: 9 loads per cell instead of 27.  Lines are cut into segments of
 // ST_SEG cells for parallelism (the two A's beyond a segment's ends are recomputed).
-constexpr int ST_SEG = 24;
+constexpr int ST_SEG = 16;
 __global__ __launch_bounds__(256) void k_uphead_stats(const bf16_t* __restrict__ x, int B, int h, int w, int d, int C,
                                                       float* __restrict__ part, float* __restrict__ gx) {
     __shared__ float lds[256 * 16];
