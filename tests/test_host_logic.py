@@ -155,3 +155,18 @@ def test_sliding_window_grid_matches_the_reference_formulation():
         _, _, count = I.window_grid(size, roi)
         assert got.shape[0] == count[0] * count[1] * count[2]
     assert I.summarize([0.5, 0.7]) == (0.6, 0.09999999999999998)
+
+
+def test_halo_brick_cost_model_picks_the_measured_bricks():
+    """ops.halo_brick (host logic, no GPU): the brick geometry per decoder conv of the 96^3 / batch-4 model as measured in
+    round 3 (tools/ab_conv_bricks.py): exact 2 x 8-tile bricks at the 12 x 12 x 24 and 6 x 6 x 24 stages, 6 x 6 x 16 where the volume
+    fills three / one full rounds of them, the im2col kernel for tiny volumes."""
+    import mivp_amd
+    from mivp_amd import ops
+    assert ops.halo_brick(4, (12, 12, 24), 192) == 66
+    assert ops.halo_brick(4, (6, 6, 24), 384) == 36
+    assert ops.halo_brick(4, (24, 24, 24), 96) == 6
+    assert ops.halo_brick(4, (48, 48, 48), 48) == 6
+    assert ops.halo_brick(1, (4, 4, 8), 48) == 0
+    for code, (bh, bw, bd, tiles) in ops._HALO_BRICKS.items():
+        assert bd in (8, 16) and tiles >= 1 and bh * bw * bd % 16 == 0, code
