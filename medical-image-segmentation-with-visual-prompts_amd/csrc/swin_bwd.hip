@@ -733,13 +733,23 @@ __global__ __launch_bounds__(64 * NW, (DKS == 1 && !DROP && !(AUG && MASKED)) ? 
                         const int4 r4 = *reinterpret_cast<const int4*>(ridq + 16 * lt + 4 * g);
                         const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dls[4] = {d4.x, d4.y, d4.z, d4.w};
                         const int rqs[4] = {r4.x, r4.y, r4.z, r4.w};
+                        // dropout hashes of elements (query q0 + 16lt + 4g + j, key krow): adjacent lanes hold the two keys of a hash
+                        // pair, so the even lane hashes j = 0, 1, the odd lane j = 2, 3 and quad-permute moves hand them around
+                        // (swin_bwd_fused.hip): 2 hashes + 4 moves per tile instead of 4 hashes
+                        uint32_t hj[4] = {0u, 0u, 0u, 0u};
+                        if (DROP) {
+                            const uint32_t row0 = dbase + (uint32_t)(q0 + 16 * lt + 4 * g + 2 * (r & 1)) * (uint32_t)(Nkp >> 1);
+                            const uint32_t h0 = drop_hash(attn_pair(row0, krow), attn_key);
+                            const uint32_t h1 = drop_hash(attn_pair(row0 + (uint32_t)(Nkp >> 1), krow), attn_key);
+                            hj[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xA0, 0xF, 0xF, false);
+                            hj[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xA0, 0xF, 0xF, false);
+                            hj[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xF5, 0xF, 0xF, false);
+                            hj[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xF5, 0xF, 0xF, false);
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float keep = 1.f;
-                            if (DROP) {                                         // element (query q0 + 16lt + 4g + j, key krow)
-                                const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(q0 + 16 * lt + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), attn_key);
-                                keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
-                            }
+                            if (DROP) keep = drop_keep(hj[j], krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                             float p, dsv;
                             if (MSK) {
                                 // a masked logit is the constant 0 (accumulator value ls[j]): it keeps its P, carries no gradient

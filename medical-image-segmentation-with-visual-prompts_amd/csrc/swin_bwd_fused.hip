@@ -156,7 +156,7 @@ MIVP_DEV void stage_query_side(const QSide& s, char* Qimg, char* Oimg, float* de
 //   1 no dQ reduce / store   2 no barrier in the tile loop   3 no dS exchange and dQ products   4 at most three key tiles per wave
 //   5 no exponentials / products / conversions (P = dS = S bits)
 template <int NW, bool DROP, bool MASKED, bool DMA = false, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
+__global__ __launch_bounds__(64 * NW, 4) void k_win_attn_bwd_fused(
     MivpSwinDesc d, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp, const bf16_t* __restrict__ qa,
     const bf16_t* __restrict__ ka, const int* __restrict__ tok_rid, const bf16_t* __restrict__ o,
@@ -424,14 +424,25 @@ __global__ __launch_bounds__(64 * NW, DROP ? 2 : 4) void k_win_attn_bwd_fused(
                 f32x4 pv, ds;
                 const uint32_t kcls = (kk4 >> (8 * i)) & 0xFFu;
                 const bool never = kcls == 255u;               // prompt / padding keys are never masked
+                // Dropout hashes of elements (query 16t + 4g + j, key 16 kt + r), j = 0..3.  Keys 2m and 2m + 1 share a hash and sit on
+                // ADJACENT lanes here, so the pair splits the four queries: the even lane hashes j = 0, 1, the odd lane j = 2, 3, and
+                // quad-permute moves (one vector instruction each, no LDS) hand every hash to both -- 2 hashes + 4 moves per tile
+                // instead of 4 hashes (8 instructions apiece)
+                uint32_t hj[4] = {0u, 0u, 0u, 0u};
+                if (DROP) {
+                    const int krow = 16 * (wave + NW * i) + r;
+                    const uint32_t row0 = dbase + (uint32_t)(16 * t + 4 * g + 2 * (r & 1)) * (uint32_t)(Nkp >> 1);
+                    const uint32_t h0 = drop_hash(attn_pair(row0, krow), attn_key);
+                    const uint32_t h1 = drop_hash(attn_pair(row0 + (uint32_t)(Nkp >> 1), krow), attn_key);
+                    hj[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xA0, 0xF, 0xF, false);      // quad_perm [0,0,2,2]: the even lane's
+                    hj[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xA0, 0xF, 0xF, false);
+                    hj[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xF5, 0xF, 0xF, false);      // quad_perm [1,1,3,3]: the odd lane's
+                    hj[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xF5, 0xF, 0xF, false);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float keep = 1.f;
-                    if (DROP) {                                // element (query 16t + 4g + j, key 16 kt + r)
-                        const int krow = 16 * (wave + NW * i) + r;
-                        const uint32_t hsh = drop_hash(attn_pair(dbase + (uint32_t)(16 * t + 4 * g + j) * (uint32_t)(Nkp >> 1), krow), attn_key);
-                        keep = drop_keep(hsh, krow & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
-                    }
+                    if (DROP) keep = drop_keep(hj[j], r & 1, d.attn_drop_thr) ? d.attn_drop_scale : 0.f;
                     const float dpe = DROP ? dp[j] * keep + n4[j] : dp[j];
                     float pe, dsv;
                     if (ABL == 5) {
