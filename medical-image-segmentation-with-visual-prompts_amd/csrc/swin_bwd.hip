@@ -1094,8 +1094,8 @@ extern "C" int mivp_swin_proj_mlp_bwd(const MivpSwinDesc* d, const void* dy, con
     const long T = (long)d->B * d->P * d->Nqp;
     const unsigned grid = (unsigned)((T + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
-    // C = 48 / 96 / 192 / 384, no proj dropout, no weight-gradient outputs: row-image kernel, natural-order image of wproj_t
-    if (mivp_tok_rows_supported(d) && !d->proj_drop_thr && !dn_out && !dyw && !d_pj)
+    // C = 48 / 96 / 192 / 384, no weight-gradient outputs: row-image kernel (proj dropout included, round 3), natural-order image of wproj_t
+    if (mivp_tok_rows_supported(d) && !dn_out && !dyw && !d_pj)
         return mivp_tok_wide_proj_mlp_bwd(d, dy, tok_dst, t1, ln_w, wmlp_t, (const bf16_t*)wproj_t + mivp_tok_natural_offset(d->C),
                                           d_o, d_t1, st);
 #define L_PMB(K) hipLaunchKernelGGL((k_swin_proj_mlp_bwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)dy, tok_dst, \

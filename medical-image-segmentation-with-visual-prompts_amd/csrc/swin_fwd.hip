@@ -1284,8 +1284,8 @@ extern "C" int mivp_swin_proj_mlp_fwd(const MivpSwinDesc* d, const void* o, cons
     const unsigned grid = (unsigned)((T + 63) / 64);
     const int CT = (d->C + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
-    // C = 48 / 96 / 192 / 384 without proj dropout: row-image kernel, natural-order image of wmlp (it follows the paired one)
-    if (mivp_tok_rows_supported(d) && !d->proj_drop_thr)
+    // C = 48 / 96 / 192 / 384: row-image kernel (proj dropout included, round 3), natural-order image of wmlp (it follows the paired one)
+    if (mivp_tok_rows_supported(d))
         return mivp_tok_wide_proj_mlp_fwd(d, o, x, tok_src, tok_dst, wproj, bproj, ln_w, ln_b,
                                           (const bf16_t*)wmlp + mivp_tok_natural_offset(d->C), bmlp, t1, y, st);
 #define LAUNCH_PM(K) hipLaunchKernelGGL((k_swin_proj_mlp_fwd<K>), dim3(grid), dim3(256), 0, st, *d, (const bf16_t*)o, \

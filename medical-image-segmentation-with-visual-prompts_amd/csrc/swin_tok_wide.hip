@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256, CT <= 6 ? 3 : 2) void k_qkv_fwd_ws(MivpSwinDes
 
 // ---------------------------------------------------------------------------------------------
 // proj + residual -> LayerNorm -> Linear + residual -> scatter          [k_swin_proj_mlp_fwd, swin_fwd.hip]
-// (no proj dropout here: the launcher leaves those calls to the 16-token kernel)
+// (proj dropout, round 3: the counter-hash mask of element (token row, channel) -- the index of k_swin_proj_mlp_fwd and
+//  mivp_dropout_masks -- applied to proj(o) + b in the first GEMM's epilogue; a uniform branch when the rate is zero)
 // ---------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ o, const bf16_t* __restrict__ x,
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
     const long row0 = (long)blockIdx.x * ROWS;
     const int row = tid / TPR, sub = tid % TPR;                  // the row phases' lane map
     const RowTok ti = row_token(d, row0 + row);
+    const uint32_t proj_key = drop_seed(d.proj_seed, d.seed_epoch);      // (uniform; unused without dropout)
     constexpr bool FLAT = flat_rows<CT>();
     // C = 96: the wave's weight fragments of a GEMM are requested a phase EARLY (proj: before the rows come in, MLP: before the
     // LayerNorm) -- read in the k loop each GEMM started with an L2 round trip that nothing overlapped
@@ -462,10 +464,26 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
                 a1 = mfma16(a, RI::frag(Aimg, R1, 32 * s + 8 * g), a1);
             }
             const bf16x4 s0 = RI::get4(Ximg, R0, n0), s1 = RI::get4(Ximg, R1, n0);
+            if (d.proj_drop_thr) {                               // proj dropout: on proj(o) + b, before the residual
+                const uint32_t p0 = (uint32_t)(((row0 + R0) * C + n0) >> 1), p1 = (uint32_t)(((row0 + R1) * C + n0) >> 1);
+                const uint32_t h00 = drop_hash(p0, proj_key), h01 = drop_hash(p0 + 1, proj_key);
+                const uint32_t h10 = drop_hash(p1, proj_key), h11 = drop_hash(p1 + 1, proj_key);
+                const float sc = d.proj_drop_scale;
+                const float k0[4] = {drop_keep(h00, 0, d.proj_drop_thr) ? sc : 0.f, drop_keep(h00, 1, d.proj_drop_thr) ? sc : 0.f,
+                                     drop_keep(h01, 0, d.proj_drop_thr) ? sc : 0.f, drop_keep(h01, 1, d.proj_drop_thr) ? sc : 0.f};
+                const float k1[4] = {drop_keep(h10, 0, d.proj_drop_thr) ? sc : 0.f, drop_keep(h10, 1, d.proj_drop_thr) ? sc : 0.f,
+                                     drop_keep(h11, 0, d.proj_drop_thr) ? sc : 0.f, drop_keep(h11, 1, d.proj_drop_thr) ? sc : 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a0[e] = (float)(bf16_t)(a0[e] + bp4[e] + (float)s0[e]);
-                a1[e] = (float)(bf16_t)(a1[e] + bp4[e] + (float)s1[e]);
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = (float)(bf16_t)((a0[e] + bp4[e]) * k0[e] + (float)s0[e]);
+                    a1[e] = (float)(bf16_t)((a1[e] + bp4[e]) * k1[e] + (float)s1[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = (float)(bf16_t)(a0[e] + bp4[e] + (float)s0[e]);
+                    a1[e] = (float)(bf16_t)(a1[e] + bp4[e] + (float)s1[e]);
+                }
             }
             t1[j][0] = a0;
             t1[j][1] = a1;
@@ -545,7 +563,8 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_fwd_wide(MivpSwinDesc d, co
 
 // ---------------------------------------------------------------------------------------------
 // proj + MLP backward:  dy -> (dO, dt1)                                 [k_swin_proj_mlp_bwd, swin_bwd.hip]
-// (no proj dropout, no weight-gradient outputs here: the launcher leaves those calls to the 16-token kernel)
+// (no weight-gradient outputs here: the launcher leaves those calls to the 16-token kernel.  Proj dropout, round 3: the residual
+//  branch sees dt1 as it is; the operand of dO = dt1 Wproj is dt1 under the forward's mask, kept in the dy image's place)
 // ---------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256, 3) void k_proj_mlp_bwd_wide(MivpSwinDesc d, const bf16_t* __restrict__ dy, const int* __restrict__ tok_dst,
@@ -565,6 +584,8 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_bwd_wide(MivpSwinDesc d, co
     const long row0 = (long)blockIdx.x * ROWS;
     const int row = tid / TPR, sub = tid % TPR;
     const RowTok ti = row_token(d, row0 + row);
+    const uint32_t proj_key = drop_seed(d.proj_seed, d.seed_epoch);      // (uniform; unused without dropout)
+    const bool drop = d.proj_drop_thr != 0;
     {   // ---- rows in: dy (gathered), t1 + its LayerNorm statistics ----
         const int dst = sel(ti.live, tok_dst[ti.pw * d.Nqp + ti.slot], -1);
         const long yoff = (ti.b * d.vol_out + max(dst, 0)) * (long)C;
@@ -650,7 +671,20 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_bwd_wide(MivpSwinDesc d, co
                 f32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = (float)dyv[e] + rstd * (dh[j][u][e] - m1 - xh[j][u][e] * m2);
-                RI::put4(Timg, R, n0, pack4(out));              // in place: this lane read these eight bytes of t1 above
+                const bf16x4 outb = pack4(out);
+                RI::put4(Timg, R, n0, outb);                    // in place: this lane read these eight bytes of t1 above
+                if (drop) {
+                    // the GEMM B operand under the forward's mask, in the place of the dy piece this lane just read (from the
+                    // f32 values, then rounded, as k_swin_proj_mlp_bwd does)
+                    const uint32_t pi = (uint32_t)(((row0 + R) * C + n0) >> 1);
+                    const uint32_t h0 = drop_hash(pi, proj_key), h1 = drop_hash(pi + 1, proj_key);
+                    f32x4 mv;
+                    mv[0] = drop_keep(h0, 0, d.proj_drop_thr) ? out[0] * d.proj_drop_scale : 0.f;
+                    mv[1] = drop_keep(h0, 1, d.proj_drop_thr) ? out[1] * d.proj_drop_scale : 0.f;
+                    mv[2] = drop_keep(h1, 0, d.proj_drop_thr) ? out[2] * d.proj_drop_scale : 0.f;
+                    mv[3] = drop_keep(h1, 1, d.proj_drop_thr) ? out[3] * d.proj_drop_scale : 0.f;
+                    RI::put4(Dimg, R, n0, pack4(mv));
+                }
             }
         }
     }
@@ -669,13 +703,16 @@ __global__ __launch_bounds__(256, 3) void k_proj_mlp_bwd_wide(MivpSwinDesc d, co
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const bf16x8 a = wfrag(wproj_t, KS, nt, s, lane);
-                a0 = mfma16(a, RI::frag(Timg, R0, 32 * s + 8 * g), a0);
-                a1 = mfma16(a, RI::frag(Timg, R1, 32 * s + 8 * g), a1);
+                const char* Bimg = drop ? Dimg : Timg;
+                a0 = mfma16(a, RI::frag(Bimg, R0, 32 * s + 8 * g), a0);
+                a1 = mfma16(a, RI::frag(Bimg, R1, 32 * s + 8 * g), a1);
             }
             acc[j][0] = a0;
             acc[j][1] = a1;
         }
-        // Dimg was last read (dy) before the barrier above: free for the dO rows
+        // Dimg was last read (dy) before the barrier above: free for the dO rows -- unless it holds the masked operand, which every
+        // wave must have finished reading first
+        if (drop) __syncthreads();
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
             const int n0 = 16 * (cg + NCG * j) + 4 * g;

@@ -273,6 +273,60 @@ def test_block_dropout_matches_oracle_under_the_same_masks(tag, p_attn, p_proj):
     assert rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), plain) > 2e-2
 
 
+@pytest.mark.parametrize("dims,C,heads,shift,p_attn,p_proj", [
+    ((14, 14, 14), 48, 4, (3, 3, 3), 0.0, 0.2),      # C = 48: proj dropout in the row-image proj + MLP pair (forward and backward)
+    ((12, 12, 24), 96, 4, (0, 0, 0), 0.1, 0.1),      # C = 96, head_dim 24: + attention dropout in the two-pass backward (shared pair hashes)
+    ((14, 14, 14), 48, 4, (3, 3, 3), 0.15, 0.0),     # fused backward with dropout at two workgroups per CU, shifted windows
+])
+def test_block_dropout_real_sizes_under_exported_masks(dims, C, heads, shift, p_attn, p_proj):
+    """The same check as test_block_dropout_matches_oracle_under_the_same_masks at model widths, data gradients only: these are
+    the shapes that take the row-image token kernels and the one-pass / two-workgroup attention backward (round 3: proj dropout
+    inside k_proj_mlp_fwd_wide / k_proj_mlp_bwd_wide, pair hashes shared between adjacent lanes in the backward kernels)."""
+    import ctypes as C_
+    import mivp_amd  # noqa: F401
+    from mivp_amd import swin_ops, _lib as L
+    from oracle import swin_ref as S
+    from oracle.unetr_ref import _block_state
+    window = (7, 7, 7)
+    gen = torch.Generator().manual_seed(7)
+    sd = {}
+    _block_state(sd, "", C, heads, list(window), 64, 1, False, gen)
+    for k in list(sd):
+        if "norm.weight" in k:
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=gen)
+        if "norm.bias" in k or k.endswith("proj.bias") or k.endswith("mlp.bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=gen)
+    sd = _rounded_state(sd)
+    x = r16(torch.randn(1, C, *dims, generator=gen))
+    gout = r16(torch.randn(1, C, *dims, generator=gen))
+    w = swin_ops.weights_from_state(sd, "", heads, 64, 0, torch.device(DEV), need_bwd=True)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy = gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    y, saved = swin_ops.swin_block_forward(xc, None, w, None, window, shift, save=True, dropout=(p_attn, p_proj, 4321, 789))
+    dx, _, _ = swin_ops.swin_block_backward(saved, w, None, dy, True, False)
+    d = saved.desc
+    B, P, Nq, Nqp, Nkp, Cc = d.B, d.P, d.Nq, d.Nqp, d.Nkp, d.C
+    ak = torch.empty((B * P * heads, Nqp, Nkp), dtype=torch.uint8, device=DEV)
+    pk = torch.empty((B * P * Nqp, Cc), dtype=torch.uint8, device=DEV)
+    L.call("mivp_dropout_masks", C_.byref(d), L.ptr(ak), L.ptr(pk), L.stream())
+    torch.cuda.synchronize()
+    attn_keep = ak.cpu().view(B, P, heads, Nqp, Nkp).float()[:, :, :, :Nq, :Nq] * float(d.attn_drop_scale)
+    proj_keep = pk.cpu().view(B, P, Nqp, Cc)[:, :, :Nq].float() * float(d.proj_drop_scale)
+    if p_attn:
+        assert abs(1.0 - float(ak.float().mean()) - p_attn) < 0.01
+    if p_proj:
+        assert abs(1.0 - float(pk.float().mean()) - p_proj) < 0.01
+    xo = x.clone().requires_grad_(True)
+    want = S.swin_block(xo, None, sd, "", window, shift, heads, 64, attn_keep if p_attn else None, proj_keep if p_proj else None)
+    want.backward(gout)
+    e_y = rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), want.detach())
+    e_dx = rel_l2(dx.float().cpu().permute(0, 4, 1, 2, 3), xo.grad)
+    print(f"[dropout real sizes] C={C} shift={shift} p=({p_attn}, {p_proj}): y {e_y:.2e} dx {e_dx:.2e}")
+    assert e_y < 6e-3 and e_dx < 1.5e-2
+    plain = S.swin_block(x, None, sd, "", window, shift, heads)
+    assert rel_l2(y.float().cpu().permute(0, 4, 1, 2, 3), plain) > 3 * e_y   # dropout was not a no-op (attention dropout alone moves y by ~0.8 %)
+
+
 def test_dropout_epoch_word_moves_the_masks():
     """mivp.h ``MivpSwinDesc.seed_epoch`` (ABI 12): the dropout kernels fold a device-resident epoch word into their seeds, so
     a recorded graph (frozen descriptor) draws new masks per replay.  Exported masks: NULL == word 0; different words give
