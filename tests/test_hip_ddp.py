@@ -146,11 +146,17 @@ def _worker_graph(rank, world, port, q, case, dropout):
                     synced[i] = step.flat[off:off + p.numel()].view_as(p).float().cpu().numpy().copy()
                     off += p.numel()
         print(f"[rank {rank}] replayed == eager local gradient, per attempt: {exact}", flush=True)
-        step.host_seconds = step.collective_seconds = 0.0
-        step.replays = 0
-        for _ in range(20):
-            last = step()
-        host_ms = step.host_ms_per_replay()                        # host time per replayed step outside the (gloo: blocking) collective
+        # host time per replayed step outside the (gloo: blocking) collective: three windows of 20 replays, the quietest one counts
+        # (two ranks and the test runner share the box's CPU quota: a window that catches another process's burst measured 0.45 ms
+        #  where the others gave 0.25)
+        windows = []
+        for _ in range(3):
+            step.host_seconds = step.collective_seconds = 0.0
+            step.replays = 0
+            for _ in range(20):
+                last = step()
+            windows.append(step.host_ms_per_replay())
+        host_ms = min(windows)
         torch.cuda.synchronize()
         names = {id(p): n for n, p in model.named_parameters()}
         pnames = [names[id(p)] for p in step.params]
